@@ -1,0 +1,120 @@
+/*
+ * include/whvi_hip.h -- C ABI of libwhvi_hip.so, the MI355X (gfx950) replacement for the
+ * reference's native FWHT module.
+ *
+ * Drop-in boundary.  The reference binds ONE native entry point for this path:
+ *
+ *     at::Tensor fwht(at::Tensor X)            src/fwht/cuda/fwht_cuda.cpp:5-14,16-18
+ *       -> fwht_cuda_frontend(X)               src/fwht/cuda/fwht_cuda_kernel.cu:156-181
+ *          -> fwht_batch1_kernel / _batch2_    src/fwht/cuda/fwht_cuda_kernel.cu:35-146
+ *
+ * exported from a Python module named `fwht_cuda` (imported at src/fwht/cuda/fwht.py:2).
+ * whvi_fwht_<dtype>() below is what that binding calls instead of fwht_cuda_frontend; the
+ * Python shim `fwht_cuda.py` at the repo root re-creates the module on top of it (see
+ * INTEGRATION.md).  The fused entry points replace the chains of ATen ops in
+ * src/weights.py:73,84,92-93 (matmul_diag_left . fwht . matmul_diag_left . fwht).
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no torch types.  All buffers are caller-owned DEVICE
+ *     pointers, 16-byte aligned, contiguous row-major (rows, 1 << log2d).  No ownership
+ *     transfer, no allocation, no host synchronisation, no global mutable state other than
+ *     a thread-local error string: safe to call from several host threads (the autograd
+ *     engine calls backward from its own thread) and capturable in a hipGraph.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream).
+ *   - the kernel launches on the device that is current for the calling thread; the
+ *     Python shim sets it from the tensor (the reference never does: fwht_cuda_kernel.cu:156).
+ *   - dst == src is allowed everywhere (in-place); partial overlap is not.
+ *   - return value 0 = launched; negative = WHVI_ERR_*; whvi_last_error() describes it.
+ *     Unlike the reference (no cudaGetLastError, silent no-op for D < 4 or D > 4096,
+ *     SURVEY.md 2a) every unsupported shape is an error and launch failures are reported.
+ *
+ * Transform definition: unnormalised Walsh-Hadamard transform in natural (Sylvester)
+ * order of every row, y = x . H_D, computed as the radix-2 butterfly network in ASCENDING
+ * stride order (h = 1, 2, 4, ...) with plain add/sub -- the order of src/fwht/cpp/fwht.cpp:7-18,
+ * so f32/f64 results are bit-identical to that reference and integer results are exact.
+ */
+#ifndef WHVI_HIP_H
+#define WHVI_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WHVI_HIP_ABI_VERSION 1
+
+/* error codes */
+#define WHVI_OK               0
+#define WHVI_ERR_ARG         -1   /* null pointer, negative size, bad enum            */
+#define WHVI_ERR_SIZE        -2   /* log2d outside [0, whvi_max_log2d(dtype)]          */
+#define WHVI_ERR_ALIGN       -3   /* a pointer is not 16-byte aligned                  */
+#define WHVI_ERR_LAUNCH      -4   /* hipGetLastError() after the launch was not success*/
+#define WHVI_ERR_OVERLAP     -5   /* dst and src overlap without being equal           */
+
+/* dtype enum used by the *_ex entry point and whvi_max_log2d */
+#define WHVI_F32   0
+#define WHVI_F64   1
+#define WHVI_F16   2   /* IEEE half storage, f32 arithmetic, one rounding on store     */
+#define WHVI_I32   3   /* two's complement, wraps like the reference's int tensors     */
+#define WHVI_BF16  4   /* bfloat16 storage, f32 arithmetic, one rounding on store      */
+
+int         whvi_hip_abi_version(void);
+const char *whvi_last_error(void);          /* thread-local; "" when the last call succeeded */
+int         whvi_max_log2d(int32_t dtype);  /* largest supported log2(D) for the dtype       */
+
+/* Batched row FWHT: dst[r, :] = FWHT(src[r, :]) for r in [0, rows).
+ * Replaces fwht_cuda_frontend (fwht_cuda_kernel.cu:156-181) + the X.clone() of
+ * fwht_cuda.cpp:11 (pass dst != src for the reference's out-of-place semantics). */
+int whvi_fwht_f32 (void *dst, const void *src, int64_t rows, int32_t log2d, void *stream);
+int whvi_fwht_f64 (void *dst, const void *src, int64_t rows, int32_t log2d, void *stream);
+int whvi_fwht_f16 (void *dst, const void *src, int64_t rows, int32_t log2d, void *stream);
+int whvi_fwht_bf16(void *dst, const void *src, int64_t rows, int32_t log2d, void *stream);
+int whvi_fwht_i32 (void *dst, const void *src, int64_t rows, int32_t log2d, void *stream);
+
+/* Same transform with an explicit kernel variant, for tuning and for cross-checking the
+ * cross-lane code paths against each other on hardware:
+ *   variant bit 0: 0 = DPP / v_permlane*_swap butterflies, 1 = ds_bpermute (__shfl_xor) only
+ *   variant bit 1: 0 = software-prefetch the next tile into registers, 1 = no prefetch
+ *   variant bit 2: 0 = plain loads/stores, 1 = non-temporal loads/stores
+ *   variant bits 8..: blocks per CU for the persistent grid (0 = default)
+ */
+int whvi_fwht_ex(void *dst, const void *src, int64_t rows, int32_t log2d,
+                 int32_t dtype, int32_t variant, void *stream);
+
+/* Fused scale -> FWHT -> scale -> FWHT -> scale, one HBM read + one write per row:
+ *
+ *     dst[r, :] = A (.) FWHT( B_s (.) FWHT( C (.) src[r, :] ) ),   s = sample of row r
+ *
+ * replacing matmul_diag_left(s1, fwht(matmul_diag_left(u, fwht(X)))) of src/weights.py:73,84.
+ * Every multiply is a separate IEEE rounding (no FMA contraction), as in the reference's
+ * separate ATen kernels.  Row r belongs to MC sample s = (r / sample_stride) % n_samples.
+ *
+ *   axis = WHVI_AXIS_ROW : the reference-exact dataflow (matmul_diag_left scales ROWS,
+ *       src/utils.py:4-12).  Rows form groups of group_rows (= D for a D x D weight
+ *       matrix); with i = r % group_rows:  A = a[i], B_s = b[s*group_rows + i], C = c[i]
+ *       (per-row scalars).
+ *   axis = WHVI_AXIS_COL : the textbook S1.H.diag(g).H.S2 applied to row vectors
+ *       (matmul_diag_right, src/utils.py:15-23): A = a[j], B_s = b[s*D + j], C = c[j]
+ *       for column j (group_rows is ignored).
+ *   a, b, c may each be NULL (treated as all ones, the multiply is skipped).
+ *   src may be NULL only with axis = WHVI_AXIS_ROW and group_rows == D: the input is then
+ *       the identity matrix per group, i.e. with c = s2 it is torch.diag(s2) of
+ *       src/weights.py:73 without materialising it (no HBM read at all).
+ */
+#define WHVI_AXIS_ROW 0
+#define WHVI_AXIS_COL 1
+
+int whvi_fused_shs_f32(void *dst, const void *src, const void *a, const void *b,
+                       const void *c, int64_t rows, int32_t log2d, int64_t n_samples,
+                       int64_t sample_stride, int64_t group_rows, int32_t axis,
+                       void *stream);
+int whvi_fused_shs_f64(void *dst, const void *src, const void *a, const void *b,
+                       const void *c, int64_t rows, int32_t log2d, int64_t n_samples,
+                       int64_t sample_stride, int64_t group_rows, int32_t axis,
+                       void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WHVI_HIP_H */

@@ -1,0 +1,34 @@
+"""pytest configuration: registers the ``gpu`` marker and puts the repo root on sys.path.
+
+``-m "not gpu"``: oracle vs the reference's golden vectors, host logic, and the C-ABI library's
+exported symbols (no GPU needed).  ``-m gpu``: parity tests proper, through the C ABI on an MI355X.
+"""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    import torch
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU visible")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def hip_lib():
+    """The native library must be there on a GPU box -- fail loudly, never fall back."""
+    from whvi_amd import _hip
+    return _hip.lib()

@@ -1,0 +1,131 @@
+"""GPU parity of the batched row FWHT (C ABI ``whvi_fwht_*``) against the CPU oracle.
+
+Bar: bit-exact for int32, integer-valued and random float32/float64 (the kernel applies the
+butterfly stages in the oracle's ascending-stride order, src/fwht/cpp/fwht.cpp:7-18); fp16/bf16
+follow the build's contract "f32 arithmetic, one rounding on store" and are compared bit-exactly
+with ``oracle(x.float()).to(half)``.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+import fwht_cuda
+from whvi_amd import _hip
+from whvi_amd.fwht.cuda import FWHTFunction
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _rand(rows, d, dtype, seed):
+    g = torch.Generator().manual_seed(seed)
+    if dtype == torch.int32:
+        return torch.randint(-8, 8, (rows, d), generator=g, dtype=torch.int32)
+    return torch.randn(rows, d, generator=g, dtype=torch.float32).to(dtype)
+
+
+def _oracle(x: torch.Tensor) -> torch.Tensor:
+    if x.dtype in (torch.float16, torch.bfloat16):
+        return torch.from_numpy(oracle.fwht(x.float().numpy())).to(x.dtype)
+    return torch.from_numpy(oracle.fwht(x.numpy()))
+
+
+@pytest.mark.parametrize("log2d", list(range(0, 14)))
+@pytest.mark.parametrize("dtype", [torch.float32, torch.int32, torch.float64, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("variant", [0, 1])
+def test_bit_exact_all_sizes(log2d, dtype, variant, hip_lib):
+    if log2d > _hip.max_log2d(dtype):
+        pytest.skip("beyond the single-wave row limit for this dtype")
+    d = 1 << log2d
+    for rows in (1, 19, 67):   # odd batches like test/walsh.py:73; 67 rows -> a partial last tile
+        x = _rand(rows, d, dtype, seed=1000 * log2d + rows)
+        got = _hip.fwht_rows(x.to(DEV), variant=variant).cpu()
+        want = _oracle(x)
+        assert got.dtype == x.dtype and got.shape == x.shape
+        assert torch.equal(got.view(torch.uint8), want.view(torch.uint8)), \
+            f"log2d={log2d} rows={rows} dtype={dtype} variant={variant}: " \
+            f"max|diff|={float((got.double() - want.double()).abs().max())}"
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("log2d", [9, 10, 11, 12])
+def test_tuning_variants_agree(log2d, variant, hip_lib):
+    d = 1 << log2d
+    x = _rand(2051, d, torch.float32, seed=7 + log2d)   # several tiles per wave + partial tile
+    got = _hip.fwht_rows(x.to(DEV), variant=variant | (1 << 8)).cpu()   # 1 block/CU: forces the tile loop
+    assert torch.equal(got, _oracle(x))
+
+
+def test_reference_known_answers(hip_lib):
+    # test/walsh.py:12-13,17-18
+    a = torch.tensor([[1.0, 2.0, 3.0, 4.0], [0.0, 1.0, 2.0, 3.0]], device=DEV)
+    out = fwht_cuda.fwht(a).cpu()
+    assert torch.equal(out, torch.tensor([[10.0, -2.0, -4.0, 0.0], [6.0, -2.0, -4.0, 0.0]]))
+
+
+def test_cuda_simple_and_large_like_reference(hip_lib):
+    # test/walsh.py:61-79 (D=4 batch 2, default allclose; D=1024 batch 19, atol 1e-4) vs dense H
+    from whvi_amd.utils import build_H
+    g = torch.Generator().manual_seed(0)
+    for d, batch, kw in ((4, 2, {}), (1024, 19, {"atol": 1e-4})):
+        H = build_H(d, DEV)
+        A = torch.randn(batch, d, generator=g).to(DEV)
+        reference = (H @ A.T).T
+        output = FWHTFunction.apply(A)
+        assert torch.allclose(output, reference, **kw)
+
+
+def test_out_of_place_and_in_place(hip_lib):
+    x = _rand(33, 512, torch.float32, 3).to(DEV)
+    keep = x.clone()
+    y = fwht_cuda.fwht(x)
+    assert torch.equal(x, keep), "input must be left untouched (fwht_cuda.cpp:11)"
+    _hip.fwht_rows(x, out=x)
+    assert torch.equal(x, y)
+
+
+def test_noncontiguous_and_misaligned_inputs(hip_lib):
+    base = _rand(64, 256, torch.float32, 5)
+    xt = base.to(DEV).T                       # strides (1, 256)
+    assert torch.equal(fwht_cuda.fwht(xt).cpu(), _oracle(base.T.contiguous()))
+    flat = torch.zeros(64 * 4 + 1, device=DEV)
+    flat[1:] = base[:, :4].reshape(-1).to(DEV)
+    view = flat[1:].view(64, 4)               # data_ptr is 4 bytes off a 16-byte boundary
+    assert view.data_ptr() % 16 != 0
+    assert torch.equal(fwht_cuda.fwht(view).cpu(), _oracle(base[:, :4].contiguous()))
+
+
+def test_error_behaviour(hip_lib):
+    with pytest.raises(RuntimeError, match="X must be a CUDA tensor"):
+        fwht_cuda.fwht(torch.randn(2, 4))
+    with pytest.raises(RuntimeError, match="X must be two-dimensional"):
+        fwht_cuda.fwht(torch.randn(2, 4, 4, device=DEV))
+    with pytest.raises(RuntimeError, match="n must be a power of 2"):
+        fwht_cuda.fwht(torch.randn(2, 6, device=DEV))
+    with pytest.raises(RuntimeError, match="outside the supported range"):
+        fwht_cuda.fwht(torch.randn(1, 1 << 15, device=DEV))
+    assert fwht_cuda.fwht(torch.empty(0, 8, device=DEV)).shape == (0, 8)
+
+
+def test_gradcheck_float64(hip_lib):
+    # src/fwht/grad_check.py:26-34
+    x = torch.randn(3, 32, dtype=torch.float64, device=DEV, requires_grad=True)
+    assert torch.autograd.gradcheck(FWHTFunction.apply, (x,))
+    assert torch.autograd.gradgradcheck(FWHTFunction.apply, (x,))
+
+
+def test_involution_and_linearity_full_size(hip_lib):
+    """Size-independent properties at a BASELINE-scale shape (D=4096, 2^15 rows, 512 MiB):
+    H.H = D.I exactly on small integers, and FWHT(x + y) == FWHT(x) + FWHT(y) on integers."""
+    d, rows = 4096, 1 << 15
+    g = torch.Generator(device=DEV).manual_seed(11)
+    x = torch.randint(-4, 5, (rows, d), generator=g, device=DEV, dtype=torch.int32).float()
+    y = torch.randint(-4, 5, (rows, d), generator=g, device=DEV, dtype=torch.int32).float()
+    fx, fy = _hip.fwht_rows(x), _hip.fwht_rows(y)
+    assert torch.equal(_hip.fwht_rows(fx), x * d)
+    assert torch.equal(_hip.fwht_rows(x + y), fx + fy)
+    # spot-check 64 rows against the oracle
+    idx = torch.arange(0, rows, rows // 64)
+    assert torch.equal(fx[idx.to(DEV)].cpu(), _oracle(x[idx.to(DEV)].cpu()))

@@ -1,0 +1,181 @@
+"""ctypes binding of ``libwhvi_hip.so`` (C ABI: ``include/whvi_hip.h``).
+
+This is the only place the package touches the native library.  There is NO fallback: if the
+library is missing or a call fails, a ``RuntimeError`` is raised -- a CUDA/HIP tensor is never
+silently routed to a CPU implementation.
+
+torch is used here for plumbing only: ``data_ptr()``, the current HIP stream and the device
+guard.  The library links ``libamdhip64.so.7``; torch is imported first so that the HIP runtime
+torch already loaded (same SONAME) is the one the kernels are registered with and the one whose
+streams we launch on.
+"""
+import ctypes
+import os
+import threading
+
+import torch  # noqa: F401  (must be loaded before the HIP library, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libwhvi_hip.so")
+
+AXIS_ROW, AXIS_COL = 0, 1
+F32, F64, F16, I32, BF16 = 0, 1, 2, 3, 4
+
+_DTYPE_CODE = {
+    torch.float32: F32, torch.float64: F64, torch.float16: F16,
+    torch.int32: I32, torch.bfloat16: BF16,
+}
+_DTYPE_SUFFIX = {
+    torch.float32: "f32", torch.float64: "f64", torch.float16: "f16",
+    torch.int32: "i32", torch.bfloat16: "bf16",
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+def _declare(lib):
+    vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32
+    lib.whvi_hip_abi_version.restype = ctypes.c_int
+    lib.whvi_hip_abi_version.argtypes = []
+    lib.whvi_last_error.restype = ctypes.c_char_p
+    lib.whvi_last_error.argtypes = []
+    lib.whvi_max_log2d.restype = ctypes.c_int
+    lib.whvi_max_log2d.argtypes = [i32]
+    for sfx in ("f32", "f64", "f16", "bf16", "i32"):
+        fn = getattr(lib, "whvi_fwht_" + sfx)
+        fn.restype = ctypes.c_int
+        fn.argtypes = [vp, vp, i64, i32, vp]
+    lib.whvi_fwht_ex.restype = ctypes.c_int
+    lib.whvi_fwht_ex.argtypes = [vp, vp, i64, i32, i32, i32, vp]
+    for sfx in ("f32", "f64"):
+        fn = getattr(lib, "whvi_fused_shs_" + sfx)
+        fn.restype = ctypes.c_int
+        fn.argtypes = [vp, vp, vp, vp, vp, i64, i32, i64, i64, i64, i32, vp]
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raise loudly when it is not there."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise RuntimeError(
+                        f"whvi_amd: native HIP library not found at {LIB_PATH}. Build it with "
+                        "`python -c 'import __graft_entry__ as g; g.build()'` or "
+                        "`make -C whvi_amd/csrc -j8`. There is no CPU fallback for GPU tensors.")
+                handle = ctypes.CDLL(LIB_PATH)
+                _declare(handle)
+                if handle.whvi_hip_abi_version() != 1:
+                    raise RuntimeError("whvi_amd: libwhvi_hip.so ABI version mismatch")
+                _lib = handle
+    return _lib
+
+
+def is_built() -> bool:
+    return os.path.exists(LIB_PATH)
+
+
+def last_error() -> str:
+    return lib().whvi_last_error().decode()
+
+
+def max_log2d(dtype: torch.dtype) -> int:
+    return lib().whvi_max_log2d(_DTYPE_CODE[dtype])
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed (code {rc}): {last_error()}")
+
+
+def _stream(t: torch.Tensor):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _aligned(t: torch.Tensor) -> torch.Tensor:
+    """Contiguous and 16-byte aligned view/copy of t (fresh torch allocations are 512-B aligned)."""
+    t = t.contiguous()
+    if t.data_ptr() % 16 != 0:
+        t = t.clone(memory_format=torch.contiguous_format)
+    return t
+
+
+def fwht_rows(src: torch.Tensor, out: torch.Tensor = None, variant: int = None) -> torch.Tensor:
+    """FWHT of every row of a contiguous (rows, D) device tensor.  ``out`` may alias ``src``
+    (in place); by default a new tensor is returned and ``src`` is left untouched."""
+    if src.device.type != "cuda":
+        raise RuntimeError("X must be a CUDA tensor")
+    if src.dim() != 2:
+        raise RuntimeError("X must be two-dimensional")
+    rows, d = src.shape
+    if d < 1 or (d & (d - 1)) != 0:
+        raise RuntimeError("n must be a power of 2")
+    if src.dtype not in _DTYPE_CODE:
+        raise RuntimeError(f"fwht: unsupported dtype {src.dtype} (float32/float64/float16/bfloat16/int32)")
+    log2d = d.bit_length() - 1
+    if out is None:
+        src = _aligned(src)
+        out = torch.empty_like(src, memory_format=torch.contiguous_format)
+    else:
+        if not (src.is_contiguous() and out.is_contiguous()):
+            raise RuntimeError("fwht: src and out must be contiguous when out= is given")
+        if out.shape != src.shape or out.dtype != src.dtype or out.device != src.device:
+            raise RuntimeError("fwht: out must match src in shape, dtype and device")
+    L = lib()
+    with torch.cuda.device(src.device):
+        if variant is None:
+            rc = getattr(L, "whvi_fwht_" + _DTYPE_SUFFIX[src.dtype])(
+                out.data_ptr(), src.data_ptr(), rows, log2d, _stream(src))
+        else:
+            rc = L.whvi_fwht_ex(out.data_ptr(), src.data_ptr(), rows, log2d,
+                                _DTYPE_CODE[src.dtype], int(variant), _stream(src))
+    _check(rc, "whvi_fwht")
+    return out
+
+
+def fused_shs(src, a=None, b=None, c=None, *, axis: str = "col", n_samples: int = 1,
+              sample_stride: int = 1, group_rows: int = 1, rows: int = None, d: int = None,
+              dtype=None, device=None, out: torch.Tensor = None) -> torch.Tensor:
+    """out[r] = a (.) FWHT(b_s (.) FWHT(c (.) src[r])) in ONE kernel (include/whvi_hip.h).
+
+    ``src=None`` (axis="row", group_rows == d) synthesises the identity matrix per group, so
+    with ``c = s2`` the input is ``torch.diag(s2)`` of src/weights.py:73 without reading HBM.
+    """
+    ax = {"row": AXIS_ROW, "col": AXIS_COL}[axis]
+    if src is not None:
+        if src.device.type != "cuda" or src.dim() != 2:
+            raise RuntimeError("fused_shs: src must be a 2-D CUDA tensor")
+        src = _aligned(src)
+        rows, d = src.shape
+        dtype, device = src.dtype, src.device
+    if dtype not in (torch.float32, torch.float64):
+        raise RuntimeError("fused_shs: float32 / float64 only")
+    if d < 1 or (d & (d - 1)) != 0:
+        raise RuntimeError("n must be a power of 2")
+    log2d = d.bit_length() - 1
+
+    def prep(v, n):
+        if v is None:
+            return None
+        v = _aligned(v.to(device=device, dtype=dtype).reshape(-1))
+        if v.numel() != n:
+            raise RuntimeError(f"fused_shs: scale vector has {v.numel()} elements, expected {n}")
+        return v
+
+    if ax == AXIS_ROW:
+        a_, b_, c_ = prep(a, group_rows), prep(b, n_samples * group_rows), prep(c, group_rows)
+    else:
+        a_, b_, c_ = prep(a, d), prep(b, n_samples * d), prep(c, d)
+    if out is None:
+        out = torch.empty((rows, d), dtype=dtype, device=device)
+    elif not out.is_contiguous() or tuple(out.shape) != (rows, d) or out.dtype != dtype:
+        raise RuntimeError("fused_shs: bad out tensor")
+    ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+    fn = getattr(lib(), "whvi_fused_shs_" + _DTYPE_SUFFIX[dtype])
+    with torch.cuda.device(device):
+        rc = fn(out.data_ptr(), ptr(src), ptr(a_), ptr(b_), ptr(c_), rows, log2d, n_samples,
+                sample_stride, group_rows, ax, _stream(out))
+    _check(rc, "whvi_fused_shs")
+    return out

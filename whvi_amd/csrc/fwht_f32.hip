@@ -1,0 +1,14 @@
+// whvi_amd/csrc/fwht_f32.hip -- batched row FWHT, float storage (one translation unit per dtype so
+// the library builds in parallel).  ABI: include/whvi_hip.h.
+#include "dispatch.hpp"
+
+extern "C" __attribute__((visibility("hidden")))
+int whvi_fwht_variant_f32(void *dst, const void *src, int64_t rows, int32_t log2d, int32_t variant, void *stream)
+{
+    return whvi::fwht_dispatch<float, true>(dst, src, rows, log2d, variant, stream);
+}
+
+extern "C" __attribute__((visibility("default"))) int whvi_fwht_f32(void *dst, const void *src, int64_t rows, int32_t log2d, void *stream)
+{
+    return whvi::fwht_dispatch<float, true>(dst, src, rows, log2d, 0, stream);
+}

@@ -1,0 +1,241 @@
+// whvi_amd/csrc/fwht_tile.hpp -- register-resident Walsh-Hadamard butterfly network for one
+// wavefront-owned tile on gfx950 (CDNA4, 64-lane waves).
+//
+// Computes what the reference's fwht_batch1_kernel computes (src/fwht/cuda/fwht_cuda_kernel.cu:
+// 74-146) but in the stage order of the reference C++ oracle (src/fwht/cpp/fwht.cpp:7-18,
+// strides 1, 2, 4, ...), so f32/f64 results are bit-identical to that oracle.
+//
+// Data layout (chosen for coalesced 16-byte-per-lane HBM access, no LDS):
+//   a tile is 64 * K chunks of 16 bytes; lane l owns chunks k*64 + l, k = 0..K-1, i.e. one
+//   wave-instruction global_load_dwordx4 reads 1 KiB contiguous.  With VEC elements per
+//   chunk the element index inside the tile is
+//         idx = k * (64*VEC) + l * VEC + c          c in [0,VEC), l in [0,64), k in [0,K)
+//   so index bits [0,LV) live in registers (c), bits [LV,LV+6) are the LANE id, bits
+//   [LV+6, LV+6+LK) live in registers again (k).  Rows are 2^LOG2D <= tile elements, never
+//   split across tiles; index bits >= LOG2D select the row and are never butterflied.
+//
+// Stage s (index bit s), always in ascending s:
+//   s <  LV        : in-register add/sub on (c, c ^ 2^s)
+//   lane bit 0,1   : DPP quad_perm        (v_add_f32_dpp with the sign folded in by v_xor)
+//   lane bit 2     : DPP row_half_mirror o quad_perm[3,2,1,0]  (= lane ^ 4)
+//   lane bit 3     : DPP row_ror:8        (= lane ^ 8)
+//   lane bit 4,5   : v_permlane16_swap / v_permlane32_swap turn the lane bit into a REGISTER
+//                    bit (a 2x2 transpose between a k-pair of registers and the lane bit), the
+//                    butterfly is then a plain in-register add/sub.  The layout stays
+//                    transposed until the partner k-bit's own stage, which repeats the same
+//                    swap (and thereby restores the layout) -- or is swapped back at once when
+//                    that k-bit is a row bit.
+//   s >= LV+6      : in-register add/sub on (k, k ^ 2^j)
+// POLICY_SHFL replaces every cross-lane step by ds_bpermute (__shfl_xor); it exists to
+// cross-check the DPP/permlane paths on hardware.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+
+namespace whvi {
+
+constexpr int POLICY_DPP = 0;
+constexpr int POLICY_SHFL = 1;
+
+constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v >> 1); }
+
+template <int I> using IC = std::integral_constant<int, I>;
+
+template <int B, int E, typename F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (B < E) {
+        f(IC<B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
+// ---- 32-bit cross-lane moves -------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xF, 0xF, true);
+}
+
+// value of lane (self ^ (1 << LB)), LB in [0,3], through the DPP network only
+template <int LB>
+__device__ __forceinline__ uint32_t dpp_xor_u32(uint32_t v)
+{
+    static_assert(LB >= 0 && LB <= 3, "DPP covers lane bits 0..3");
+    if constexpr (LB == 0) return dpp_u32<0xB1>(v);               // quad_perm:[1,0,3,2]
+    else if constexpr (LB == 1) return dpp_u32<0x4E>(v);          // quad_perm:[2,3,0,1]
+    else if constexpr (LB == 2) return dpp_u32<0x1B>(dpp_u32<0x141>(v)); // half_mirror (l^7) then [3,2,1,0] (l^3)
+    else return dpp_u32<0x128>(v);                                // row_ror:8
+}
+
+template <typename A> struct Bits;
+template <> struct Bits<float> {
+    template <int LB> static __device__ __forceinline__ float partner_dpp(float v)
+    {
+        return __builtin_bit_cast(float, dpp_xor_u32<LB>(__builtin_bit_cast(uint32_t, v)));
+    }
+    // upper lane of the pair computes partner - v, lower lane v + partner; folding the sign
+    // into v first keeps it at one v_xor + one (DPP-fused) v_add.  p + (-v) == p - v exactly.
+    static __device__ __forceinline__ float combine(float v, float p, uint32_t sign_mask, bool)
+    {
+        return p + __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, v) ^ sign_mask);
+    }
+};
+template <> struct Bits<int32_t> {
+    template <int LB> static __device__ __forceinline__ int32_t partner_dpp(int32_t v)
+    {
+        return (int32_t)dpp_xor_u32<LB>((uint32_t)v);
+    }
+    static __device__ __forceinline__ int32_t combine(int32_t v, int32_t p, uint32_t, bool upper)
+    {
+        // wraps on overflow exactly like the reference's int tensors (unsigned arithmetic)
+        uint32_t uv = (uint32_t)v, up = (uint32_t)p;
+        return (int32_t)(upper ? up - uv : uv + up);
+    }
+};
+template <> struct Bits<double> {
+    template <int LB> static __device__ __forceinline__ double partner_dpp(double v)
+    {
+        uint64_t u = __builtin_bit_cast(uint64_t, v);
+        uint32_t lo = dpp_xor_u32<LB>((uint32_t)u);
+        uint32_t hi = dpp_xor_u32<LB>((uint32_t)(u >> 32));
+        return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+    }
+    static __device__ __forceinline__ double combine(double v, double p, uint32_t sign_mask, bool)
+    {
+        uint64_t u = __builtin_bit_cast(uint64_t, v) ^ ((uint64_t)sign_mask << 32);
+        return p + __builtin_bit_cast(double, u);
+    }
+};
+
+// v_permlane{16,32}_swap on one 32-bit register pair: afterwards
+//   a' = [a.even_part, b.even_part],  b' = [a.odd_part, b.odd_part]
+// where "part" is a 16-lane row (W=16) or a 32-lane half (W=32).
+template <int W>
+__device__ __forceinline__ void swap_u32(uint32_t &a, uint32_t &b)
+{
+    if constexpr (W == 16) {
+        auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+        a = r[0];
+        b = r[1];
+    } else {
+        auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+        a = r[0];
+        b = r[1];
+    }
+}
+
+template <int W, typename A>
+__device__ __forceinline__ void swap_pair(A &a, A &b)
+{
+    if constexpr (sizeof(A) == 4) {
+        uint32_t ua = __builtin_bit_cast(uint32_t, a), ub = __builtin_bit_cast(uint32_t, b);
+        swap_u32<W>(ua, ub);
+        a = __builtin_bit_cast(A, ua);
+        b = __builtin_bit_cast(A, ub);
+    } else {
+        uint64_t ua = __builtin_bit_cast(uint64_t, a), ub = __builtin_bit_cast(uint64_t, b);
+        uint32_t al = (uint32_t)ua, ah = (uint32_t)(ua >> 32), bl = (uint32_t)ub, bh = (uint32_t)(ub >> 32);
+        swap_u32<W>(al, bl);
+        swap_u32<W>(ah, bh);
+        a = __builtin_bit_cast(A, ((uint64_t)ah << 32) | al);
+        b = __builtin_bit_cast(A, ((uint64_t)bh << 32) | bl);
+    }
+}
+
+// radix-2 butterfly exactly as src/fwht/cpp/fwht.cpp:11-13: (lo, hi) -> (lo + hi, lo - hi)
+template <typename A>
+__device__ __forceinline__ void bfly(A &lo, A &hi)
+{
+    if constexpr (std::is_same<A, int32_t>::value) {
+        uint32_t a = (uint32_t)lo, b = (uint32_t)hi;
+        lo = (int32_t)(a + b);
+        hi = (int32_t)(a - b);
+    } else {
+        A a = lo, b = hi;
+        lo = a + b;
+        hi = a - b;
+    }
+}
+
+// One full FWHT of every 2^LOG2D-element row held in r[K][VEC] (layout above).
+template <typename A, int VEC, int K, int LOG2D, int POLICY>
+__device__ __forceinline__ void fwht_tile(A (&r)[K][VEC], const int lane)
+{
+    constexpr int LV = ilog2(VEC);
+    constexpr int LK = ilog2(K);
+    static_assert(LOG2D <= LV + 6 + LK, "row does not fit the tile");
+    // partner k-bits of the permlane-swap stages and whether their own stage exists
+    constexpr int KB5 = (K >= 4) ? 1 : 0;
+    constexpr bool PAIR4 = (POLICY == POLICY_DPP) && (K >= 2) && (LV + 6 + 0 < LOG2D);
+    constexpr bool PAIR5 = (POLICY == POLICY_DPP) && (K >= 4) && (LV + 6 + 1 < LOG2D);
+
+    static_for<0, LOG2D>([&](auto s_) {
+        constexpr int S = decltype(s_)::value;
+        if constexpr (S < LV) {
+            // ---- in-chunk register stage ----
+            constexpr int H = 1 << S;
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+#pragma unroll
+                for (int c = 0; c < VEC; ++c)
+                    if ((c & H) == 0) bfly(r[k][c], r[k][c | H]);
+        } else if constexpr (S < LV + 6) {
+            // ---- lane stage ----
+            constexpr int LB = S - LV;
+            const bool upper = (lane >> LB) & 1;
+            const uint32_t sign_mask = upper ? 0x80000000u : 0u;
+            if constexpr (POLICY == POLICY_SHFL || (LB >= 4 && K < 2)) {
+#pragma unroll
+                for (int k = 0; k < K; ++k)
+#pragma unroll
+                    for (int c = 0; c < VEC; ++c) {
+                        A p = __shfl_xor(r[k][c], 1 << LB, 64);
+                        r[k][c] = Bits<A>::combine(r[k][c], p, sign_mask, upper);
+                    }
+            } else if constexpr (LB < 4) {
+#pragma unroll
+                for (int k = 0; k < K; ++k)
+#pragma unroll
+                    for (int c = 0; c < VEC; ++c) {
+                        A p = Bits<A>::template partner_dpp<LB>(r[k][c]);
+                        r[k][c] = Bits<A>::combine(r[k][c], p, sign_mask, upper);
+                    }
+            } else {
+                constexpr int W = (LB == 4) ? 16 : 32;
+                constexpr int KB = (LB == 4) ? 0 : KB5;
+                constexpr bool PAIRED = (LB == 4) ? PAIR4 : PAIR5;
+                constexpr int KH = 1 << KB;
+#pragma unroll
+                for (int k = 0; k < K; ++k)
+                    if ((k & KH) == 0) {
+#pragma unroll
+                        for (int c = 0; c < VEC; ++c) {
+                            swap_pair<W>(r[k][c], r[k | KH][c]);
+                            bfly(r[k][c], r[k | KH][c]);
+                            if constexpr (!PAIRED) swap_pair<W>(r[k][c], r[k | KH][c]);
+                        }
+                    }
+            }
+        } else {
+            // ---- k-bit register stage ----
+            constexpr int J = S - LV - 6;
+            constexpr int KH = 1 << J;
+            constexpr bool VIA16 = (J == 0) && PAIR4;    // this index bit currently sits on lane bit 4
+            constexpr bool VIA32 = (J == KB5) && PAIR5;  // ... on lane bit 5
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+                if ((k & KH) == 0) {
+#pragma unroll
+                    for (int c = 0; c < VEC; ++c) {
+                        if constexpr (VIA16) swap_pair<16>(r[k][c], r[k | KH][c]);
+                        else if constexpr (VIA32) swap_pair<32>(r[k][c], r[k | KH][c]);
+                        bfly(r[k][c], r[k | KH][c]);
+                    }
+                }
+        }
+    });
+}
+
+}  // namespace whvi

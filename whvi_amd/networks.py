@@ -1,0 +1,117 @@
+"""WHVI networks (mirror of the reference's src/networks.py): the Monte-Carlo sample loop, the
+ELBO, the two-phase training loop and evaluation.  Consumers of ``WHVILinear``; kept
+interface- and checkpoint-compatible (state_dict keys ``sequential.{i}....`` and
+``likelihood.sigma``)."""
+import pathlib
+from typing import Iterable, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from whvi_amd.layers import WHVI
+from whvi_amd.likelihoods import GaussianLikelihood, Likelihood
+
+__all__ = ["WHVINetwork", "WHVIRegression"]
+
+
+def _progress(iterable, desc):
+    try:
+        from tqdm import tqdm
+        return tqdm(iterable, desc=desc)
+    except ImportError:  # tqdm is optional here
+        class _Plain:
+            def __init__(self, it):
+                self.it = it
+
+            def __iter__(self):
+                return iter(self.it)
+
+            def set_description(self, *_):
+                pass
+        return _Plain(iterable)
+
+
+class WHVINetwork(nn.Module, WHVI):
+    def __init__(self, modules: Iterable[nn.Module], likelihood: Likelihood, train_samples=1, eval_samples=64):
+        """Sequential network with WHVI layers (src/networks.py:12-31)."""
+        super().__init__()
+        self.sequential = nn.Sequential(*modules)
+        self.likelihood = likelihood
+        self.train_samples = train_samples
+        self.eval_samples = eval_samples
+        self.current_mnll = 0.0
+        self.current_kl = 0.0
+
+    @property
+    def kl(self):
+        return sum([m.kl for m in self.sequential.children() if 'kl' in dir(m)])
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """(batch, in_dim) -> (batch, out_dim, n_samples): one stochastic pass per Monte-Carlo
+        sample, samples stacked on the last axis (src/networks.py:36-54)."""
+        assert x.dim() == 2, "Input shape must be (batch_size, in_dim)"
+        batch_size = x.size(0)
+        n_samples = self.train_samples if self.training else self.eval_samples
+        draws = []
+        for _ in range(n_samples):
+            out = self.sequential.forward(x)
+            draws.append(out.reshape(batch_size, out.size(-1)))
+        predictions = torch.stack(draws, dim=2)
+        assert predictions.dim() == 3
+        return predictions
+
+    def loss(self, x, y, n: int, ignore_kl=False) -> torch.Tensor:
+        """Negative ELBO estimate = MNLL (+ KL) (src/networks.py:56-69)."""
+        self.current_mnll = self.likelihood.mnll_batch_estimate(y, self(x), n)
+        self.current_kl = self.kl
+        return self.current_mnll if ignore_kl else self.current_mnll + self.current_kl
+
+    def _epochs(self, data_loader, optimizer, scheduler, epochs, label, ignore_kl, pbar_update_period,
+                checkpoint_dir=None, set_to_none=False):
+        bar = _progress(range(epochs), f'[{label}] KL = {self.current_kl:.2f}, MNLL = {self.current_mnll:.2f}')
+        for epoch in bar:
+            for data_x, data_y in data_loader:
+                loss = self.loss(data_x, data_y, n=len(data_loader.dataset), ignore_kl=ignore_kl)
+                loss.backward()
+                optimizer.step()
+                scheduler.step()
+                self.zero_grad(set_to_none=set_to_none)
+            if checkpoint_dir is not None and epoch % 5000 == 0:
+                torch.save(self.state_dict(), pathlib.Path(checkpoint_dir) / f'epoch-{epoch}.pth')
+            if epoch % pbar_update_period == 0:
+                bar.set_description(f'[{label}] KL = {self.current_kl:.2f}, MNLL = {self.current_mnll:.2f}')
+
+    def train_model(self, data_loader, optimizer, scheduler, epochs1: int = 500, epochs2: int = 5000,
+                    pbar_update_period=20, ignore_kl=False, checkpoint_dir=None):
+        """Two phases as in src/networks.py:71-99.  As in the reference, the ``requires_grad``
+        assignments below set a plain attribute on the likelihood MODULE and do not freeze its
+        ``sigma`` parameter -- kept so that training trajectories agree."""
+        self.train()
+        self.likelihood.requires_grad = False
+        self._epochs(data_loader, optimizer, scheduler, epochs1, 'Fixed LH', ignore_kl, pbar_update_period,
+                     set_to_none=True)
+        self.likelihood.requires_grad = True
+        self._epochs(data_loader, optimizer, scheduler, epochs2, 'Optimized LH', ignore_kl, pbar_update_period,
+                     checkpoint_dir=checkpoint_dir)
+        self.eval()
+
+    def eval_model(self, X_test, y_test, loss) -> Tuple[float, float]:
+        """(test error, test MNLL) with ``eval_samples`` draws (src/networks.py:101-115)."""
+        self.eval()
+        y_pred = self(X_test)
+        test_mnll = self.likelihood.mnll_batch_estimate(y_test, y_pred, n=y_test.size(0))
+        return float(loss(y_pred, y_test)), float(test_mnll)
+
+
+def _rmse_of_mean(y_pred, y_true):
+    return torch.sqrt(F.mse_loss(y_pred.mean(dim=2).flatten(), y_true.flatten()))
+
+
+class WHVIRegression(WHVINetwork):
+    def __init__(self, modules: Iterable[nn.Module], sigma: float = 1.0, **kwargs):
+        """Regression network with a Gaussian likelihood (src/networks.py:118-128)."""
+        super().__init__(modules, likelihood=GaussianLikelihood(sigma), **kwargs)
+
+    def eval_model(self, X_test, y_test, loss=_rmse_of_mean) -> Tuple[float, float]:
+        return super().eval_model(X_test, y_test, loss)

@@ -1,0 +1,226 @@
+"""WHVI weight matrices (mirror of the reference's src/weights.py).
+
+Public surface, parameter names/shapes/initialisation and numerics follow the reference so that
+``state_dict``s interchange and ``WHVILinear`` / ``WHVIRegression`` consume these classes
+unchanged:
+
+    WHVISquarePow2Matrix  src/weights.py:13-108
+    WHVIStackedMatrix     src/weights.py:111-208
+    WHVIColumnMatrix      src/weights.py:211-251
+
+Dataflow note (SURVEY.md finding 1).  ``fwht`` transforms ROWS and ``matmul_diag_left`` scales
+ROWS, so ``w_bar(u) = S1 . fwht(diag(u) . fwht(diag(s2)))`` is, as written in the reference,
+``D * diag(s1 * u * s2)``.  Parity is judged against the reference as written, therefore this
+module reproduces that row-scaling dataflow and does not "fix" it.
+
+Device dispatch (src/weights.py:34-41): GPU tensors run on the MI355X HIP kernels -- the whole
+scale -> FWHT -> scale -> FWHT -> scale chain of ``w_bar`` is ONE kernel launch that synthesises
+``diag(s2)`` in registers (``whvi_fused_shs_f32``, include/whvi_hip.h) -- and host tensors run
+the same torch ops as the reference (dense H for D < 4096, vectorised butterflies otherwise).
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from whvi_amd.utils import matmul_diag_left, kl_diag_normal
+from whvi_amd.fwht.cuda import FWHTFunction as fwht_cuda
+from whvi_amd.fwht.python import FWHTFunction as fwht_python
+from whvi_amd.fwht.python import WHT_matmul as wht_matmul
+
+__all__ = ["WHVISquarePow2Matrix", "WHVIStackedMatrix", "WHVIColumnMatrix", "WBarFunction"]
+
+
+class WBarFunction(torch.autograd.Function):
+    """``W[k] = diag(s1) . fwht(diag(u[k]) . fwht(diag(s2)))`` for every row ``u[k]`` of a
+    ``(S, D)`` GPU tensor, as one fused HIP launch producing ``(S, D, D)``.
+
+    Forward: ``whvi_fused_shs`` with the identity input synthesised in-kernel (no HBM read),
+    row-axis scales c = s2, b = u[k], a = s1 -- multiply / butterfly order and roundings exactly
+    those of src/weights.py:73.  Backward: the adjoint chain (H is symmetric, so every FWHT's
+    adjoint is the same FWHT, src/fwht/cuda/fwht.py:14-16) written with differentiable ops."""
+
+    @staticmethod
+    def forward(ctx, s1, u, s2):
+        from whvi_amd import _hip
+        S, D = u.shape
+        ctx.save_for_backward(s1, u, s2)
+        out = _hip.fused_shs(None, a=s1, b=u, c=s2, axis="row", n_samples=S, sample_stride=D,
+                             group_rows=D, rows=S * D, d=D, dtype=u.dtype, device=u.device)
+        return out.view(S, D, D)
+
+    @staticmethod
+    def backward(ctx, grad_W):
+        s1, u, s2 = ctx.saved_tensors
+        S, D = u.shape
+        fw = fwht_cuda.apply
+        with torch.enable_grad():
+            gW = grad_W.reshape(S * D, D)
+            t1 = fw(torch.diag(s2))                                  # fwht(diag(s2)), (D, D)
+            g2 = (s1.unsqueeze(-1) * grad_W).reshape(S * D, D)       # adjoint of the s1 scaling
+            g1 = fw(g2).view(S, D, D)                                # adjoint of the outer FWHT
+            grad_u = (g1 * t1).sum(dim=2)                            # (S, D)
+            gx = fw((u.unsqueeze(-1) * g1).reshape(S * D, D)).view(S, D, D)
+            grad_s2 = torch.diagonal(gx, dim1=1, dim2=2).sum(dim=0)  # input was diag(s2)
+            t2 = fw((u.unsqueeze(-1) * t1).reshape(S * D, D))        # pre-s1 tensor, recomputed
+            grad_s1 = (gW * t2).view(S, D, D).sum(dim=(0, 2))
+        return grad_s1, grad_u, grad_s2
+
+
+class WHVISquarePow2Matrix(nn.Module):
+    def __init__(self, D, lambda_=1e-5, bias=False):
+        """Square (D, D) WHVI matrix, D a power of two (src/weights.py:14-32).
+
+        :param int D: number of rows/columns.
+        :param float lambda_: prior variance.
+        :param boolean bias: add a (non-variational) bias row vector in ``forward``.
+        """
+        super().__init__()
+        self.D = D
+        self.lambda_ = lambda_
+        self.padding = 0  # interface parity with the stacked matrix
+        self.wht_slow = wht_matmul()  # dense-H transform for small host matrices; H built lazily
+
+        # creation order = the reference's RNG consumption order (bias, s1, s2, g_mu, g_rho)
+        self.bias = nn.Parameter(torch.zeros(1, D)) if bias else None
+        self.s1 = nn.Parameter(torch.randn(D) * 0.01)
+        self.s2 = nn.Parameter(torch.randn(D) * 0.01)
+        self.g_mu = nn.Parameter(torch.zeros(D))
+        self.g_rho = nn.Parameter(torch.rand(D) - 3)
+
+    def fwht(self, x):
+        """Row FWHT with the reference's dispatch rule (src/weights.py:34-41)."""
+        if x.device.type == "cuda":
+            return fwht_cuda.apply(x)
+        if self.D < 2 ** 12:
+            return self.wht_slow.apply(x)
+        return fwht_python.apply(x)
+
+    @property
+    def g_sigma(self):
+        """Standard deviations of the variational posterior over g, softplus(g_rho)
+        (src/weights.py:43-50)."""
+        return F.softplus(self.g_rho)
+
+    @property
+    def kl(self):
+        """KL from the N(0, lambda I) prior to the posterior, via the reference's formula and
+        argument convention (src/weights.py:52-64)."""
+        dev = self.g_mu.device
+        return kl_diag_normal(self.g_mu, self.g_sigma, torch.zeros(self.D, device=dev),
+                              torch.ones(self.D, device=dev) * self.lambda_)
+
+    def _w_bar_stack(self, u):
+        """``w_bar`` for every row of ``u`` (S, D) -> (S, D, D)."""
+        if u.device.type == "cuda":
+            return WBarFunction.apply(self.s1, u, self.s2)
+        base = self.fwht(torch.diag(self.s2))
+        return torch.stack([matmul_diag_left(self.s1, self.fwht(matmul_diag_left(row, base)))
+                            for row in u])
+
+    def w_bar(self, u):
+        """``S1 . fwht(diag(u) . fwht(diag(s2)))`` (src/weights.py:66-73)."""
+        if u.device.type == "cuda":
+            return self._w_bar_stack(u.unsqueeze(0))[0]
+        return matmul_diag_left(self.s1, self.fwht(matmul_diag_left(u, self.fwht(torch.diag(self.s2)))))
+
+    def sample(self):
+        """Draw W with g ~ N(g_mu, g_sigma^2) (src/weights.py:75-85)."""
+        epsilon = torch.randn(self.D, device=self.g_mu.device)
+        g_tilde = self.g_mu + self.g_sigma * epsilon
+        return self.w_bar(g_tilde)
+
+    def sample_lrt(self, h):
+        """``h @ (w_bar(g_mu) + w_bar(g_sigma * eps)).T`` with one eps per call
+        (src/weights.py:87-93).  On the GPU both ``w_bar`` matrices come from a single launch."""
+        epsilon = torch.randn(self.D, device=self.g_mu.device)
+        if self.g_mu.device.type == "cuda":
+            pair = self._w_bar_stack(torch.stack((self.g_mu, self.g_sigma * epsilon)))
+            return h @ (pair[0] + pair[1]).T
+        return h @ (self.w_bar(self.g_mu) + self.w_bar(self.g_sigma * epsilon)).T
+
+    def forward(self, x, use_lrt=True):
+        """(src/weights.py:95-108) ``x``: (batch, D)."""
+        if use_lrt:
+            out = self.sample_lrt(x)
+            return out + self.bias if self.bias is not None else out
+        return F.linear(x, self.sample(), self.bias)
+
+
+class WHVIStackedMatrix(nn.Module):
+    def __init__(self, n_in, n_out, lambda_=1e-5, bias=False):
+        """Arbitrary (n_out, n_in) matrix as a vertical stack of square power-of-two blocks
+        (src/weights.py:112-133)."""
+        super().__init__()
+        self.n_in = n_in
+        self.n_out = n_out
+        self.lambda_ = lambda_
+        self.D_in, self.D_out, self.padding, self.stack = self.setup_dimensions(n_in, n_out)
+        self.weight_matrices = nn.ModuleList(
+            [WHVISquarePow2Matrix(self.D_in, lambda_=lambda_) for _ in range(self.stack)])
+        self.bias = nn.Parameter(torch.zeros(1, self.D_out)) if bias else None
+
+    @staticmethod
+    def setup_dimensions(D_in, D_out):
+        """(D_in_adjusted, D_out_adjusted, padding, stack) -- src/weights.py:135-160, including its
+        float-log guard: when ``2 ** ceil(log2(D_in))`` comes out as ``2 * D_in`` the input is
+        already a power of two and is left alone."""
+        next_power = 2 ** math.ceil(math.log(D_in, 2))
+        if next_power == 2 * D_in:
+            padding = 0
+        else:
+            padding = next_power - D_in
+            D_in = next_power
+        stack = -(-D_out // D_in)
+        if D_out % D_in != 0:
+            D_out = D_in * stack
+        return D_in, D_out, padding, stack
+
+    @property
+    def kl(self):
+        return sum(weight.kl for weight in self.weight_matrices)
+
+    def sample(self):
+        return torch.cat([weight.sample() for weight in self.weight_matrices])
+
+    def sample_lrt(self, h):
+        return torch.cat([weight.sample_lrt(h) for weight in self.weight_matrices], dim=1)
+
+    def forward(self, x, use_lrt=True):
+        """Zero-pad the features to D_in, multiply, drop the surplus outputs
+        (src/weights.py:182-208)."""
+        x_padded = torch.zeros((*x.size()[:-1], self.D_in), device=x.device)
+        x_padded[..., :self.n_in] = x
+        if use_lrt:
+            output = self.sample_lrt(x_padded)
+            if self.bias is not None:
+                output = output + self.bias
+        else:
+            output = F.linear(x_padded, self.sample(), self.bias)
+        return output[..., :self.n_out]
+
+
+class WHVIColumnMatrix(nn.Module):
+    def __init__(self, n_out, lambda_=1e-5, bias=False, transposed=False):
+        """Column (n_out, 1) matrix -- or row (1, n) when ``transposed`` -- cut from a square
+        sample (src/weights.py:212-228)."""
+        super().__init__()
+        self.D = n_out
+        self.D_adjusted = 2 ** math.ceil(math.log(n_out, 2))
+        self.weight_submodule = WHVISquarePow2Matrix(self.D_adjusted, lambda_=lambda_)
+        self.transposed = transposed
+        self.bias = nn.Parameter(torch.zeros(1, 1 if transposed else n_out)) if bias else None
+
+    @property
+    def kl(self):
+        return self.weight_submodule.kl
+
+    def sample(self):
+        """First ``D`` entries of the row-major flattening of a square sample
+        (src/weights.py:239-248)."""
+        matrix = torch.reshape(self.weight_submodule.sample(), (-1, 1))[:self.D]
+        return matrix.T if self.transposed else matrix
+
+    def forward(self, x):
+        return F.linear(x, self.sample(), self.bias)
