@@ -40,6 +40,7 @@ inline int check_common(const void *dst, const void *src, int64_t rows, int32_t 
                         size_t elem, bool src_optional = false)
 {
     g_err[0] = 0;
+    if (rows == 0 && log2d >= 0 && log2d <= maxl) return WHVI_OK;   // nothing to do, pointers may be null
     if (dst == nullptr || (src == nullptr && !src_optional))
         return fail(WHVI_ERR_ARG, "whvi: null %s pointer", dst ? "src" : "dst");
     if (rows < 0) return fail(WHVI_ERR_ARG, "whvi: negative row count%s (%lld)", "", rows);

@@ -32,13 +32,16 @@ template <> struct Elem<float> {
     static __device__ __forceinline__ void unpack(const u32x4 &raw, acc (&o)[VEC])
     {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = __builtin_bit_cast(float, raw[i]);
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t u = raw[i];   // by value: bit_cast of a vector-element lvalue reads lane 0
+            o[i] = __uint_as_float(u);
+        }
     }
     static __device__ __forceinline__ u32x4 pack(const acc (&v)[VEC])
     {
         u32x4 r;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) r[i] = __builtin_bit_cast(uint32_t, v[i]);
+        for (int i = 0; i < 4; ++i) r[i] = __float_as_uint(v[i]);
         return r;
     }
 };
@@ -67,7 +70,7 @@ template <> struct Elem<double> {
     {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-            o[i] = __builtin_bit_cast(double, ((uint64_t)raw[2 * i + 1] << 32) | raw[2 * i]);
+            o[i] = __longlong_as_double((long long)(((uint64_t)raw[2 * i + 1] << 32) | raw[2 * i]));
     }
     static __device__ __forceinline__ u32x4 pack(const acc (&v)[VEC])
     {
@@ -114,8 +117,9 @@ template <> struct Elem<__hip_bfloat16> {
     {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            o[2 * i] = __builtin_bit_cast(float, raw[i] << 16);
-            o[2 * i + 1] = __builtin_bit_cast(float, raw[i] & 0xFFFF0000u);
+            const uint32_t u = raw[i];
+            o[2 * i] = __uint_as_float(u << 16);
+            o[2 * i + 1] = __uint_as_float(u & 0xFFFF0000u);
         }
     }
     static __device__ __forceinline__ uint32_t rne(float f)
