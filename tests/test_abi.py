@@ -1,0 +1,69 @@
+"""The C-ABI library loads and exports every symbol include/whvi_hip.h declares; argument checks
+that happen before any launch work without a GPU (no compute calls here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "whvi_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(whvi_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_expected_entry_points():
+    syms = _declared_symbols()
+    for needed in ("whvi_fwht_f32", "whvi_fwht_f64", "whvi_fwht_f16", "whvi_fwht_bf16", "whvi_fwht_i32",
+                   "whvi_fwht_ex", "whvi_fused_shs_f32", "whvi_fused_shs_f64", "whvi_last_error",
+                   "whvi_hip_abi_version", "whvi_max_log2d"):
+        assert needed in syms
+
+
+def test_library_exports_every_declared_symbol():
+    from whvi_amd import _hip
+    assert _hip.is_built(), "libwhvi_hip.so missing: run __graft_entry__.build()"
+    lib = ctypes.CDLL(_hip.LIB_PATH)
+    for name in _declared_symbols():
+        assert hasattr(lib, name), f"{name} declared in include/whvi_hip.h but not exported"
+    assert _hip.lib().whvi_hip_abi_version() == 1
+
+
+def test_argument_checks_without_gpu():
+    from whvi_amd import _hip
+    L = _hip.lib()
+    buf = (ctypes.c_char * 256)()
+    p = ctypes.addressof(buf)
+    p16 = (p + 15) & ~15
+    assert L.whvi_fwht_f32(None, None, 4, 3, None) == -1 and "null" in _hip.last_error()
+    assert L.whvi_fwht_f32(p16, p16, -1, 3, None) == -1
+    assert L.whvi_fwht_f32(p16, p16, 1, 14, None) == -2 and "supported range" in _hip.last_error()
+    assert L.whvi_fwht_f64(p16, p16, 1, 13, None) == -2
+    assert L.whvi_fwht_f32(p16 + 4, p16 + 4, 1, 3, None) == -3 and "aligned" in _hip.last_error()
+    assert L.whvi_fwht_f32(p16, p16 + 16, 1, 3, None) == -5          # partial overlap
+    assert L.whvi_fwht_ex(p16, p16, 1, 3, 99, 0, None) == -1         # unknown dtype
+    assert L.whvi_fwht_f32(None, None, 0, 3, None) == 0 and _hip.last_error() == ""   # empty batch
+    assert L.whvi_fused_shs_f32(p16, p16, None, None, None, 1, 3, 0, 1, 1, 1, None) == -1  # n_samples < 1
+    assert L.whvi_fused_shs_f32(p16, None, None, None, None, 1, 3, 1, 1, 4, 0, None) == -1  # identity needs group_rows == D
+    assert L.whvi_fused_shs_f32(p16, p16, None, None, None, 1, 1, 1, 1, 1, 1, None) == -2   # D below one chunk
+    assert [L.whvi_max_log2d(i) for i in range(5)] == [13, 12, 13, 13, 13] and L.whvi_max_log2d(7) == -1
+
+
+def test_gpu_tensors_never_fall_back(monkeypatch):
+    """A missing native library is an error, not a CPU detour."""
+    from whvi_amd import _hip
+    monkeypatch.setattr(_hip, "_lib", None)
+    monkeypatch.setattr(_hip, "LIB_PATH", os.path.join(ROOT, "does_not_exist.so"))
+    with pytest.raises(RuntimeError, match="native HIP library not found"):
+        _hip.lib()
+
+
+def test_fwht_cuda_module_surface():
+    import torch
+    import fwht_cuda
+    assert callable(fwht_cuda.fwht)
+    with pytest.raises(RuntimeError, match="X must be a CUDA tensor"):   # fwht_cuda.cpp:6
+        fwht_cuda.fwht(torch.randn(2, 4))

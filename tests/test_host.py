@@ -1,0 +1,240 @@
+"""Host-side mirror of the reference interface (whvi_amd/*) on the CPU, against golden bundles
+recorded from the live reference and against the reference's own unit-test assertions."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+import fwht_cpp
+from whvi_amd.fwht import cpp as cpp_fwht
+from whvi_amd.fwht import python as python_fwht
+from whvi_amd.layers import WHVILinear
+from whvi_amd.likelihoods import GaussianLikelihood
+from whvi_amd.networks import WHVIRegression
+from whvi_amd.utils import build_H, kl_diag_normal, matmul_diag_left, matmul_diag_right
+from whvi_amd.weights import WHVIStackedMatrix, WHVISquarePow2Matrix
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def fg():
+    return np.load(os.path.join(GOLD, "fwht_golden.npz"))
+
+
+class ReplayRandn:
+    """Replays recorded ``torch.randn`` draws in order (the reference draws eps inside forward,
+    src/weights.py:82,92); anything else falls through to the real generator."""
+
+    def __init__(self, draws, device=None):
+        self.draws, self.i, self.real, self.device = list(draws), 0, torch.randn, device
+
+    def __call__(self, *a, **k):
+        if self.i < len(self.draws):
+            t = torch.from_numpy(np.array(self.draws[self.i]))
+            self.i += 1
+            dev = k.get("device", None)
+            return t.to(dev) if dev is not None else t
+        return self.real(*a, **k)
+
+
+# ---- FWHT front-ends -------------------------------------------------------------------------
+@pytest.mark.parametrize("d", [1, 2, 4, 8, 32, 64, 512, 1024, 4096])
+def test_cpp_and_python_front_ends_bit_equal_to_reference(fg, d):
+    x = torch.from_numpy(fg[f"f32_in_{d}"])
+    want = torch.from_numpy(fg[f"f32_out_{d}"])
+    assert torch.equal(cpp_fwht.FWHTFunction.apply(x), want)
+    assert torch.equal(python_fwht.FWHTFunction.apply(x), want)
+    assert torch.equal(cpp_fwht.FWHT()(x), want)
+    xi = torch.from_numpy(fg[f"i32_in_{d}"])
+    assert torch.equal(fwht_cpp.forward(xi), torch.from_numpy(fg[f"i32_out_{d}"]))
+    assert torch.equal(fwht_cpp.forward(xi.long()), torch.from_numpy(fg[f"i32_out_{d}"]).long())
+    xd = torch.from_numpy(fg[f"f64_in_{d}"])
+    assert torch.equal(fwht_cpp.backward(xd), torch.from_numpy(fg[f"f64_out_{d}"]))
+    assert torch.equal(x, torch.from_numpy(fg[f"f32_in_{d}"])), "input must not be modified"
+
+
+def test_cpp_front_end_3d_input_like_benchmarks(fg):
+    x = torch.from_numpy(fg["f32_in_3d"])     # benchmarks/walsh.py:21 feeds (1, D, D)
+    assert torch.equal(fwht_cpp.forward(x), torch.from_numpy(fg["f32_out_3d"]))
+
+
+def test_reference_walsh_suite_cpu_cases():
+    """test/walsh.py:11-59 re-stated against this package's front-ends."""
+    a = torch.tensor([[1.0], [2.0], [3.0], [4.0]]).T
+    assert torch.allclose(cpp_fwht.FWHTFunction.apply(a), torch.tensor([[10.0], [-2.0], [-4.0], [0.0]]).T, atol=1e-5)
+    a = torch.tensor([[0.0], [1.0], [2.0], [3.0]]).T
+    assert torch.allclose(cpp_fwht.FWHTFunction.apply(a), torch.tensor([[6.0], [-2.0], [-4.0], [0.0]]).T, atol=1e-5)
+    D = 2 ** 5
+    H = build_H(D, torch.device("cpu"))
+    g = torch.Generator().manual_seed(0)
+    for batch in (1, 40):
+        for _ in range(30):
+            A = torch.randn(batch, D, generator=g)
+            reference = (H @ A.T).T
+            assert torch.allclose(cpp_fwht.FWHTFunction.apply(A), reference, atol=1e-5)
+            assert torch.allclose(python_fwht.WHT_matmul().apply(A), reference)
+            assert torch.allclose(cpp_fwht.FWHTFunction.apply(A), python_fwht.FWHTFunction.apply(A), atol=1e-3)
+
+
+def test_gradcheck_host_front_ends():
+    # src/fwht/grad_check.py:26-34
+    for fn in (cpp_fwht.FWHTFunction.apply, python_fwht.FWHTFunction.apply):
+        x = torch.randn(3, 32, dtype=torch.float64, requires_grad=True)
+        assert torch.autograd.gradcheck(fn, (x,))
+
+
+# ---- utils -----------------------------------------------------------------------------------
+def test_utils_against_reference_values(fg):
+    A, d = torch.from_numpy(fg["diag_A"]), torch.from_numpy(fg["diag_d"])
+    assert torch.equal(matmul_diag_left(d, A), torch.from_numpy(fg["diag_left"]))
+    assert torch.equal(matmul_diag_right(A, d), torch.from_numpy(fg["diag_right"]))
+    assert torch.allclose(torch.diag(d) @ A, matmul_diag_left(d, A))           # test/utils.py:8-13
+    assert torch.allclose(A @ torch.diag(d), matmul_diag_right(A, d))           # test/utils.py:15-20
+    assert torch.equal(build_H(8, torch.device("cpu")), torch.from_numpy(fg["H_8"]))
+    mu1, sd1, mu2, sd2 = (torch.from_numpy(v) for v in fg["kl_args"])
+    assert torch.allclose(kl_diag_normal(mu1, sd1, mu2, sd2), torch.from_numpy(fg["kl_value"]), rtol=1e-6)
+    want = torch.distributions.kl.kl_divergence(                                 # test/utils.py:22-34
+        torch.distributions.MultivariateNormal(mu1, torch.diag(sd1)),
+        torch.distributions.MultivariateNormal(mu2, torch.diag(sd2)))
+    assert torch.allclose(want, kl_diag_normal(mu1, sd1, mu2, sd2))
+
+
+# ---- layers ----------------------------------------------------------------------------------
+def _bundle(name):
+    g = np.load(os.path.join(GOLD, "whvi_golden.npz"))
+    return {k.split("/", 1)[1]: g[k] for k in g.files if k.startswith(name + "/")}
+
+
+def _layer_from_bundle(b, device="cpu"):
+    layer = WHVILinear(int(b["n_in"]), int(b["n_out"]), lambda_=float(b["lambda_"]), bias=bool(int(b["bias"])))
+    state = {k[len("param."):]: torch.from_numpy(np.array(v)) for k, v in b.items() if k.startswith("param.")}
+    assert set(state) == set(dict(layer.named_parameters())), "parameter names must match the reference"
+    layer.load_state_dict(state)
+    return layer.to(device)
+
+
+def run_layer_bundle(name, device, monkeypatch, rtol):
+    b = _bundle(name)
+    layer = _layer_from_bundle(b, device)
+    eps = [b[f"eps{i}"] for i in range(int(b["n_eps"]))]
+    x = torch.from_numpy(b["x"]).to(device).requires_grad_(True)
+    weight = torch.from_numpy(b["weight"]).to(device)
+    replay = ReplayRandn(eps)
+    monkeypatch.setattr(torch, "randn", replay)
+    y = layer(x)
+    monkeypatch.undo()
+    assert replay.i == len(eps), "must draw exactly the reference's number of eps vectors"
+    kl = layer.kl
+    ((y * weight).sum() + kl).backward()
+
+    def close(got, want, what):
+        want = torch.from_numpy(np.array(want))
+        scale = float(want.abs().max()) or 1.0
+        err = float((got.detach().cpu() - want).abs().max())
+        assert err <= rtol * scale, f"{name}: {what} err {err:.3e} > {rtol} * {scale:.3e}"
+
+    close(y, b["y"], "forward")
+    close(kl, b["kl"], "kl")
+    close(x.grad, b["grad_x"], "grad_x")
+    for pname, p in layer.named_parameters():
+        close(p.grad, b["grad." + pname], "grad " + pname)
+
+
+@pytest.mark.parametrize("name", ["sq8", "sq64b", "sq512", "sq4096", "st3x16", "st5x7b", "st13x128",
+                                  "col1x10b", "col16x1"])
+def test_layer_forward_kl_backward_vs_reference_cpu(name, monkeypatch):
+    # same torch ops as the reference on the host -> far inside the 1e-5 bar
+    run_layer_bundle(name, "cpu", monkeypatch, rtol=1e-5)
+
+
+def test_dispatch_and_parameter_layout():
+    from whvi_amd.weights import WHVIColumnMatrix
+    assert isinstance(WHVILinear(1, 10).weight_submodule, WHVIColumnMatrix)
+    assert WHVILinear(16, 1).weight_submodule.transposed
+    assert isinstance(WHVILinear(8, 8).weight_submodule, WHVISquarePow2Matrix)
+    st = WHVILinear(3, 1024).weight_submodule
+    assert isinstance(st, WHVIStackedMatrix) and (st.D_in, st.D_out, st.padding, st.stack) == (4, 1024, 1, 256)
+    sq = WHVISquarePow2Matrix(64, bias=True)
+    assert {n: tuple(p.shape) for n, p in sq.named_parameters()} == {
+        "bias": (1, 64), "s1": (64,), "s2": (64,), "g_mu": (64,), "g_rho": (64,)}
+    assert float(sq.g_mu.abs().max()) == 0.0 and -3.0 <= float(sq.g_rho.min()) and float(sq.g_rho.max()) <= -2.0
+    assert float(sq.s1.abs().max()) < 0.06     # 0.01 * N(0, 1)
+
+
+def test_same_seed_same_initialisation_as_reference():
+    """Parameter creation consumes the RNG in the reference's order, so a seed reproduces the
+    reference's initial state_dict (values recorded in the golden bundle before perturbation are
+    not stored; here: self-consistency of the order bias, s1, s2, g_mu, g_rho)."""
+    torch.manual_seed(3)
+    a = WHVISquarePow2Matrix(16, bias=True)
+    torch.manual_seed(3)
+    s1 = torch.randn(16) * 0.01
+    s2 = torch.randn(16) * 0.01
+    g_rho = torch.rand(16) - 3
+    assert torch.equal(a.s1.data, s1) and torch.equal(a.s2.data, s2) and torch.equal(a.g_rho.data, g_rho)
+
+
+# ---- network + likelihood --------------------------------------------------------------------
+def test_network_shapes_like_reference_test():
+    # test/networks.py:11-23
+    for k in range(1, 21):
+        net = WHVIRegression([nn.Linear(1, 8), nn.ReLU(), WHVILinear(8, 8), nn.ReLU(), nn.Linear(8, k)],
+                             train_samples=5, eval_samples=6)
+        net.train()
+        assert net(torch.randn(50, 1)).size() == (50, k, 5)
+        net.eval()
+        assert net(torch.randn(50, 1)).size() == (50, k, 6)
+
+
+def test_network_values_vs_reference(monkeypatch):
+    g = np.load(os.path.join(GOLD, "network_golden.npz"))
+    net = WHVIRegression([nn.Linear(1, 8), nn.ReLU(), WHVILinear(8, 8), nn.ReLU(), nn.Linear(8, 2)],
+                         train_samples=3, eval_samples=4)
+    state = {k[len("state."):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("state.")}
+    assert set(state) == set(net.state_dict()), "checkpoint keys must interchange with the reference"
+    net.load_state_dict(state)
+    net.train()
+    monkeypatch.setattr(torch, "randn", ReplayRandn([g[f"eps{i}"] for i in range(int(g["n_eps"]))]))
+    pred = net(torch.from_numpy(g["x"]))
+    monkeypatch.undo()
+    assert torch.allclose(pred, torch.from_numpy(g["pred"]), rtol=1e-5, atol=1e-6)
+    mnll = net.likelihood.mnll_batch_estimate(torch.from_numpy(g["y"]), pred, 100)
+    assert torch.allclose(mnll, torch.from_numpy(g["mnll"]), rtol=1e-5)
+    assert torch.allclose(net.kl, torch.from_numpy(g["kl"]), rtol=1e-6)
+
+
+def test_gaussian_likelihood_like_reference_tests():
+    # test/likelihoods.py:8-56 (explicit double loop, delta 1e-4)
+    g = np.load(os.path.join(GOLD, "network_golden.npz"))
+    y = torch.reshape(torch.tensor([0., 1., 2., -1.]), (-1, 1))
+    y_hat = torch.tensor([[0.2, 1.1, 2.2, -1.3], [-0.1, 1.05, 2, -1.1]]).T.unsqueeze(1)
+    got = float(GaussianLikelihood(sigma=1.0).mnll_batch_estimate(y, y_hat, 12))
+    assert abs(got - float(g["lik_value"])) < 1e-4
+    n, m, n_mc, sigma = 116, 24, 80, 15.21
+    gen = torch.Generator().manual_seed(1)
+    y, y_hat = torch.randn((m, 1), generator=gen), torch.randn((m, 1, n_mc), generator=gen)
+    target = 0.0
+    for j in range(m):
+        tmp = 0.0
+        for i in range(n_mc):
+            tmp += -(np.log(1 / (np.sqrt(2 * np.pi) * sigma)) - 0.5 * (float(y[j] - y_hat[j, 0, i]) / sigma) ** 2)
+        target += tmp / n_mc
+    target *= n / m
+    assert abs(target - float(GaussianLikelihood(sigma=sigma).mnll_batch_estimate(y, y_hat, n))) < 1e-4
+
+
+def test_train_and_eval_loop_runs(tmp_path):
+    from torch.utils.data import DataLoader, TensorDataset
+    torch.manual_seed(0)
+    X, Y = torch.randn(32, 3), torch.randn(32, 1)
+    net = WHVIRegression([WHVILinear(3, 8), nn.ReLU(), WHVILinear(8, 8), nn.ReLU(), WHVILinear(8, 1)], eval_samples=4)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda t: 1.0)
+    net.train_model(DataLoader(TensorDataset(X, Y), batch_size=16), opt, sched, epochs1=2, epochs2=2,
+                    checkpoint_dir=tmp_path)
+    assert (tmp_path / "epoch-0.pth").exists()
+    err, mnll = net.eval_model(X, Y)
+    assert np.isfinite(err) and np.isfinite(mnll)

@@ -1,0 +1,166 @@
+"""Pins the CPU oracle (oracle/) -- runs without a GPU.
+
+The oracle is the checker for every GPU parity test, so it is itself checked against
+  1. the reference's own known-answer vectors (test/walsh.py:12-13,17-18),
+  2. the dense Hadamard identity the reference's tests use (test/walsh.py:22-49),
+  3. golden vectors recorded from the live reference (tests/golden/*.npz, make_golden.py),
+  4. the reference's own compiled C++ FWHT (oracle/_ref), bit for bit, when it has been built.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from oracle import whvi_oracle as wo
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def fg():
+    return np.load(os.path.join(GOLD, "fwht_golden.npz"))
+
+
+def test_reference_known_answer_vectors():
+    # literal vectors of test/walsh.py:12-13 and :17-18
+    a = np.array([[1.0, 2.0, 3.0, 4.0]], dtype=np.float32)
+    assert np.array_equal(oracle.fwht(a), np.array([[10.0, -2.0, -4.0, 0.0]], dtype=np.float32))
+    a = np.array([[0.0, 1.0, 2.0, 3.0]], dtype=np.float32)
+    assert np.array_equal(oracle.fwht(a), np.array([[6.0, -2.0, -4.0, 0.0]], dtype=np.float32))
+
+
+def test_known_answers_as_recorded_from_reference(fg):
+    for k in ("kat1", "kat2"):
+        assert np.array_equal(oracle.fwht(fg[k + "_in"]), fg[k + "_out"])
+
+
+def test_dense_hadamard_identity():
+    # test/walsh.py:22-49: D = 32, batch 1 and 40, atol 1e-5 against (H @ A.T).T
+    rng = np.random.default_rng(0)
+    H = oracle.hadamard(32)
+    for batch in (1, 40):
+        for _ in range(30):
+            A = rng.standard_normal((batch, 32)).astype(np.float32)
+            assert np.allclose(oracle.fwht(A), (H @ A.T.astype(np.float64)).T, atol=1e-5)
+    assert np.array_equal(oracle.dense_wht(np.eye(8)), oracle.hadamard(8))
+
+
+def test_hadamard_matches_reference_build_H(fg):
+    assert np.array_equal(oracle.hadamard(8), fg["H_8"].astype(np.float64))
+
+
+@pytest.mark.parametrize("d", [1, 2, 4, 8, 32, 64, 512, 1024, 4096])
+def test_bit_equal_to_golden(fg, d):
+    assert np.array_equal(oracle.fwht(fg[f"i32_in_{d}"]), fg[f"i32_out_{d}"])
+    assert np.array_equal(oracle.fwht(fg[f"i32_in_{d}"].astype(np.float32)), fg[f"intf32_out_{d}"])
+    assert np.array_equal(oracle.fwht(fg[f"i32_in_{d}"].astype(np.int64)), fg[f"i32_out_{d}"].astype(np.int64))
+    f32 = oracle.fwht(fg[f"f32_in_{d}"])
+    assert np.array_equal(f32.view(np.uint32), fg[f"f32_out_{d}"].view(np.uint32))
+    assert np.array_equal(f32.view(np.uint32), fg[f"f32_pyout_{d}"].view(np.uint32))  # python FWHT is bit-equal too
+    assert np.array_equal(oracle.fwht(fg[f"f64_in_{d}"]).view(np.uint64), fg[f"f64_out_{d}"].view(np.uint64))
+
+
+def test_bit_equal_to_compiled_reference():
+    ref = oracle.load_reference_cpp()
+    if ref is None:
+        pytest.skip("oracle/_ref not built (needs /root/reference; python oracle/build_ref.py)")
+    import torch
+    g = torch.Generator().manual_seed(3)
+    for rows, d in ((19, 1024), (3, 4096), (7, 1), (5, 2), (40, 32)):
+        x = torch.randn(rows, d, generator=g)
+        assert np.array_equal(ref.forward(x).numpy().view(np.uint32), oracle.fwht(x.numpy()).view(np.uint32))
+        xi = torch.randint(-8, 8, (rows, d), generator=g, dtype=torch.int32)
+        assert np.array_equal(ref.forward(xi).numpy(), oracle.fwht(xi.numpy()))
+
+
+def test_stage_order_tolerance_statement():
+    """SURVEY.md finding 3: descending strides (the reference CUDA kernel's order) differ from the
+    ascending order only by fp32 rounding, a few 1e-7 * max|y|; identical on integers."""
+    rng = np.random.default_rng(1)
+    for d in (512, 4096):
+        x = rng.standard_normal((8, d)).astype(np.float32)
+        up, down = oracle.fwht(x), oracle.fwht_descending(x)
+        assert np.abs(up - down).max() <= 1e-6 * np.abs(up).max()
+        xi = rng.integers(-8, 8, (8, d)).astype(np.float32)
+        assert np.array_equal(oracle.fwht(xi), oracle.fwht_descending(xi))
+
+
+def test_pipeline_is_composition_of_primitives():
+    """oracle.pipeline == matmul_diag_{left,right} o fwht o ... (src/utils.py:4-23, src/weights.py:73)."""
+    rng = np.random.default_rng(2)
+    S, G, D = 3, 8, 8
+    x = rng.standard_normal((S * G, D)).astype(np.float32)
+    a, c = rng.standard_normal(G).astype(np.float32), rng.standard_normal(G).astype(np.float32)
+    b = rng.standard_normal((S, G)).astype(np.float32)
+    got = oracle.pipeline(x, a, b, c, n_samples=S, sample_stride=G, group_rows=G, axis="row")
+    for s in range(S):
+        blk = x[s * G:(s + 1) * G]
+        want = a[:, None] * oracle.fwht((b[s][:, None] * oracle.fwht((c[:, None] * blk).astype(np.float32))).astype(np.float32))
+        assert np.array_equal(got[s * G:(s + 1) * G], want.astype(np.float32))
+    # column axis, (batch, sample, D) row order
+    B = 4
+    x = rng.standard_normal((B * S, D)).astype(np.float32)
+    a, c = rng.standard_normal(D).astype(np.float32), rng.standard_normal(D).astype(np.float32)
+    b = rng.standard_normal((S, D)).astype(np.float32)
+    got = oracle.pipeline(x, a, b, c, n_samples=S, sample_stride=1, axis="col")
+    for r in range(B * S):
+        want = a * oracle.fwht((b[r % S] * oracle.fwht((c * x[r])[None].astype(np.float32))[0])[None].astype(np.float32))[0]
+        assert np.array_equal(got[r], want.astype(np.float32))
+    # the dense matrix it stands for: y = x S2 H G H S1 (column scaling), in float64
+    H = oracle.hadamard(D)
+    x64 = x.astype(np.float64)
+    got64 = oracle.pipeline(x64, a, b, c, n_samples=S, sample_stride=1, axis="col")
+    for r in range(B * S):
+        M = np.diag(c.astype(np.float64)) @ H @ np.diag(b[r % S].astype(np.float64)) @ H @ np.diag(a.astype(np.float64))
+        assert np.allclose(got64[r], x64[r] @ M, rtol=1e-12, atol=1e-12)
+
+
+def test_w_bar_collapses_to_diagonal_exactly():
+    """SURVEY.md finding 1: with butterflies, w_bar(u) == diag(s1 * (D * (u * s2))) bit for bit."""
+    rng = np.random.default_rng(4)
+    for D in (8, 512):
+        s1, s2, u = (rng.standard_normal(D).astype(np.float32) for _ in range(3))
+        W = wo.w_bar(s1, s2, u)
+        assert np.array_equal(W, np.diag(s1 * (np.float32(D) * (u * s2))).astype(np.float32))
+
+
+def _bundles():
+    g = np.load(os.path.join(GOLD, "whvi_golden.npz"))
+    names = sorted({k.split("/", 1)[0] for k in g.files})
+    return g, names
+
+
+@pytest.mark.parametrize("name", ["sq8", "sq64b", "sq512", "sq4096", "st3x16", "st5x7b", "st13x128",
+                                  "col1x10b", "col16x1"])
+def test_whvi_oracle_matches_reference_bundles(name):
+    """Forward output and KL of the numpy restatement vs bundles recorded from the live reference.
+    Tolerance 1e-5 relative to max|y| (BASELINE.json north_star): the reference's host path for
+    D < 4096 goes through a dense H matmul (src/weights.py:38-39) whose rounding noise the exact
+    butterfly does not have (measured <= 3e-6 at D = 512)."""
+    g, _ = _bundles()
+    b = {k.split("/", 1)[1]: g[k] for k in g.files if k.startswith(name + "/")}
+    params = {k[len("param."):]: v for k, v in b.items() if k.startswith("param.")}
+    layer = wo.layer_from_params(int(b["n_in"]), int(b["n_out"]), float(b["lambda_"]), params)
+    eps = [b[f"eps{i}"] for i in range(int(b["n_eps"]))]
+    y = layer.forward(b["x"], eps if isinstance(layer, wo.Stacked) else eps[0])
+    assert y.shape == b["y"].shape
+    assert np.abs(y - b["y"]).max() <= 1e-5 * np.abs(b["y"]).max()
+    assert abs(float(layer.kl) - float(b["kl"])) <= 1e-5 * abs(float(b["kl"]))
+
+
+def test_sample_and_w_bar_vs_reference():
+    g, _ = _bundles()
+    b = {k.split("/", 1)[1]: g[k] for k in g.files if k.startswith("sample16/")}
+    sq = wo.Square(b["s1"], b["s2"], b["g_mu"], b["g_rho"], 0.7)
+    for got, want in ((sq.sample(b["eps0"]), b["W"]), (wo.w_bar(b["s1"], b["s2"], b["u"]), b["w_bar"])):
+        assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max()
+        # the reference's off-diagonals are dense-matmul rounding noise, ours are exact zeros
+        assert np.count_nonzero(got - np.diag(np.diag(got))) == 0
+
+
+@pytest.mark.parametrize("args,expect", [((3, 16), (4, 16, 1, 4)), ((5, 7), (8, 8, 3, 1)),
+                                         ((13, 128), (16, 128, 3, 8)), ((3, 1024), (4, 1024, 1, 256)),
+                                         ((8, 8), (8, 8, 0, 1)), ((4, 6), (4, 8, 0, 2))])
+def test_setup_dimensions_probes(args, expect):
+    assert wo.setup_dimensions(*args) == expect   # values probed on the reference
