@@ -1,0 +1,294 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the WHVI hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N = 1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+
+Metric (BASELINE.json): batched FWHT Gtransforms/s (one transform = one length-D row) with the
+achieved HBM GB/s against the roofline.  Workload = the configuration the metric's target is
+quoted on: D = 4096, fp32, batch 8192 x 128 MC samples = 2^20 rows (16 GiB), resident in HBM,
+transformed IN PLACE -- one "step" = one pass of the kernel over the whole buffer.  Weak scaling:
+every rank owns its own 2^20 rows (rows are independent, no data-path collective).
+
+Rank 0 prints ONE JSON line.  Besides the driver's contract fields it carries
+  roofline     : algorithmic bytes (2 * D * 4 per transform) / the kernel's average
+                 launch duration measured live with HIP events on the launch stream, vs 8 TB/s;
+                 ``traffic`` is the PMC-measured HBM bytes per launch recorded under profiles/.
+  cpu_baseline : the reference's own C++ FWHT (oracle/_ref, kind "reference") -- or the C
+                 restatement (kind "port") when that binary is absent -- timed on this host's
+                 cores on a bounded sample of the same workload (N = 1, rank 0 only).
+  extras       : the D in {512..4096} sweep of the metric, fp16, the fused S.H.G.H.S kernel
+                 (BASELINE config 3) and WHVILinear(512,512) forward+KL (config 2); N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+LOG2D = 12                     # D = 4096
+ROWS = 8192 * 128              # batch x MC samples = 2^20 transforms per GPU
+CPU_PLUMBING = os.environ.get("WHVI_BENCH_CPU_PLUMBING") == "1"   # tests/test_parallel.py only
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=ROWS, help="transforms per GPU (default 2^20)")
+    ap.add_argument("--log2d", type=int, default=LOG2D)
+    ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def setup_dist(n_gpus):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != n_gpus:
+        raise SystemExit(f"bench.py: --gpus {n_gpus} but WORLD_SIZE={world}; for N > 1 launch with "
+                         "python -m torch.distributed.run --nproc-per-node N")
+    if CPU_PLUMBING:
+        device = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py: no GPU visible")
+        device = torch.device("cuda", local)
+        torch.cuda.set_device(device)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if CPU_PLUMBING:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    return rank, world, device
+
+
+def fence(device, world):
+    if world > 1:
+        dist.barrier()
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)
+
+
+def make_step(x):
+    """One pass of the hot path over the resident buffer, in place."""
+    if x.device.type == "cuda":
+        from whvi_amd import _hip
+        return lambda: _hip.fwht_rows(x, out=x)
+    import fwht_cpp   # CPU plumbing mode (tests only): the host library, never the oracle
+
+    def step():
+        x.copy_(fwht_cpp.forward(x))
+    return step
+
+
+def timed(step, steps, warmup, device, world):
+    """(wall seconds for exactly `steps` steps, max over ranks; HIP-event ms per launch on this rank)"""
+    for _ in range(warmup):
+        step()
+    fence(device, world)
+    use_ev = device.type == "cuda"
+    if use_ev:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()          # torch's current stream == the stream the C ABI launches on
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    if use_ev:
+        ev1.record()
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)
+    wall = time.perf_counter() - t0
+    ev_ms = ev0.elapsed_time(ev1) / steps if use_ev else wall * 1e3 / steps
+    if world > 1:
+        t = torch.tensor([wall], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    return wall, ev_ms
+
+
+def event_ms(fn, iters=10, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def recorded_traffic(workload_key):
+    """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (collected and
+    corrected as MI355X_MICROARCH.md prescribes: separate --pmc passes, FETCH_SIZE doubled)."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        rec = json.load(open(path)).get(workload_key)
+        return rec["hbm_bytes_per_launch"] if rec else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
+def cpu_baseline(log2d, target_s=12.0):
+    """Time the reference's C++ FWHT (or the C restatement) on a bounded sample of the workload."""
+    import numpy as np
+    import oracle
+    d = 1 << log2d
+    ref = oracle.load_reference_cpp()
+    g = torch.Generator().manual_seed(0)
+    if ref is not None:
+        kind, cores = "reference", torch.get_num_threads()
+        run = lambda t: ref.forward(t)                       # noqa: E731
+    else:
+        oracle.build()
+        kind, cores = "port", 1
+        run = lambda t: oracle.fwht(t.numpy())               # noqa: E731
+    rows = 64
+    x = torch.randn(rows, d, generator=g)
+    t0 = time.perf_counter()
+    run(x)
+    per_row = (time.perf_counter() - t0) / rows
+    rows = int(max(64, min(1 << 16, target_s / max(per_row, 1e-9))))
+    x = torch.randn(rows, d, generator=g)
+    t0 = time.perf_counter()
+    run(x)
+    dt = time.perf_counter() - t0
+    return {"value": rows / dt / 1e9, "unit": "Gtransforms/s", "cores": cores, "kind": kind,
+            "sample": f"{rows} rows of D={d} fp32 (same row shape as the GPU workload), one call, {dt:.1f} s; "
+                      + ("reference src/fwht/cpp/fwht.cpp compiled into oracle/_ref, "
+                         f"{cores} torch threads of {os.cpu_count()} host CPUs" if kind == "reference"
+                         else "scalar C restatement oracle/fwht_oracle.c"),
+            "gb_per_s_algorithmic": rows * 2 * d * 4 / dt / 1e9}
+
+
+def extras(device):
+    """D sweep + fp16 + fused kernel + WHVILinear; all with inputs resident, HIP-event timed."""
+    from whvi_amd import _hip
+    out = {}
+    sweep = {}
+    for log2d in (9, 10, 11, 12):
+        d = 1 << log2d
+        rows = (1 << 32) // (4 * d)                       # 4 GiB of fp32 per size
+        x = torch.randn(rows, d, device=device) * 2.0 ** -64
+        ms = event_ms(lambda: _hip.fwht_rows(x, out=x))
+        gbs = rows * 2 * d * 4 / (ms * 1e-3) / 1e9
+        sweep[f"D={d}"] = {"rows": rows, "ms": round(ms, 4), "Gtransforms_per_s": round(rows / (ms * 1e-3) / 1e9, 4),
+                           "GB_per_s": round(gbs, 1), "frac_of_peak": round(gbs / HBM_PEAK_GBS, 4)}
+        del x
+    out["fwht_f32_sweep_4GiB"] = sweep
+    # BASELINE config 5 (single-GPU share): D = 4096 fp16, 2^20 rows = 8 GiB
+    x = (torch.randn(1 << 20, 4096, device=device) * 2.0 ** -8).half()
+    ms = event_ms(lambda: _hip.fwht_rows(x, out=x), iters=6)
+    gbs = x.numel() * 2 * 2 / (ms * 1e-3) / 1e9
+    out["fwht_f16_D4096_2^20rows"] = {"ms": round(ms, 4), "Gtransforms_per_s": round((1 << 20) / (ms * 1e-3) / 1e9, 4),
+                                      "GB_per_s": round(gbs, 1), "frac_of_peak": round(gbs / HBM_PEAK_GBS, 4)}
+    del x
+    # BASELINE config 3: fused S.H.diag(g).H.S, D = 2048, 64 MC samples, batch 8192 (4 GiB), in place
+    d, S, B = 2048, 64, 8192
+    x = torch.randn(B * S, d, device=device)
+    a, c = torch.randn(d, device=device) * 0.01, torch.randn(d, device=device) * 0.01
+    g = torch.randn(S, d, device=device)
+    ms = event_ms(lambda: _hip.fused_shs(x, a, g, c, axis="col", n_samples=S, sample_stride=1, out=x), iters=6)
+    gbs = x.numel() * 2 * 4 / (ms * 1e-3) / 1e9
+    out["fused_shs_D2048_S64_B8192"] = {"ms": round(ms, 4), "Gtransforms_per_s": round(B * S / (ms * 1e-3) / 1e9, 4),
+                                        "GB_per_s": round(gbs, 1), "frac_of_peak": round(gbs / HBM_PEAK_GBS, 4),
+                                        "note": "one fused launch = 2 FWHTs + 3 scalings per row; unfused "
+                                                "(2 FWHT launches + 3 elementwise) moves 5x the bytes"}
+    del x
+    # BASELINE config 2: WHVILinear(512, 512) forward + KL, 32 MC samples, batch 4096, fp32
+    from whvi_amd.layers import WHVILinear
+    layer = WHVILinear(512, 512).to(device)
+    h = torch.randn(4096, 512, device=device)
+
+    def fwd_kl():
+        with torch.no_grad():
+            acc = 0.0
+            for _ in range(32):
+                acc = acc + layer(h).sum()
+            return acc + layer.kl
+    ms = event_ms(fwd_kl, iters=5, warm=2)
+    out["whvilinear_512_fwd_kl_32mc_b4096"] = {"ms": round(ms, 3), "ms_per_mc_sample": round(ms / 32, 4)}
+    return out
+
+
+def main():
+    args = parse()
+    rank, world, device = setup_dist(args.gpus)
+    d = 1 << args.log2d
+    rows = args.rows if not CPU_PLUMBING else 256
+    if device.type == "cuda":
+        from whvi_amd import _hip
+        _hip.lib()    # fail loudly before allocating anything if the native library is missing
+    # synthetic input, resident before the timed region.  FWHT o FWHT = D * identity, so an in-place
+    # run grows by sqrt(D) per step: start small enough that K + W steps stay finite in fp32.
+    total_steps = args.steps + args.warmup
+    scale_log2 = -min(120, (args.log2d * total_steps) // 2)
+    gen = torch.Generator(device=device).manual_seed(1234 + rank)
+    x = torch.randn(rows, d, device=device, generator=gen)
+    x.mul_(2.0 ** scale_log2)
+    step = make_step(x)
+
+    wall, ev_ms = timed(step, args.steps, args.warmup, device, world)
+    finite = bool(torch.isfinite(x[:: max(1, rows // 64)]).all())
+    value = world * rows * args.steps / wall / 1e9
+    alg_bytes = rows * 2 * d * 4                      # per launch: read once + write once
+    achieved = alg_bytes / (ev_ms * 1e-3) / 1e9
+
+    rec = {
+        "metric": "batched FWHT Gtransforms/sec (achieved HBM GB/s vs roofline in `roofline`)",
+        "value": round(value, 5), "unit": "Gtransforms/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(wall * 1e3 / args.steps, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"in-place batched FWHT, D={d} fp32, {rows} rows per GPU "
+                               f"(batch 8192 x 128 MC samples), {rows * d * 4 / 2**30:.0f} GiB resident in HBM per GPU",
+                   "D": d, "rows_per_gpu": rows, "parallelism": f"row-sharded x{world}, no data-path collective",
+                   "values_finite_after_run": finite},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4),
+                     "traffic": recorded_traffic(f"fwht_f32_D{d}_rows{rows}"),
+                     "kernel": "whvi::fwht_rows_kernel<float,12,16,DPP,prefetch>",
+                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms_hip_events": round(ev_ms, 4)},
+    }
+    if rank == 0 and world == 1 and not CPU_PLUMBING:
+        del x
+        torch.cuda.empty_cache()
+        if not args.no_cpu_baseline:
+            try:
+                rec["cpu_baseline"] = cpu_baseline(args.log2d)
+            except Exception as err:   # the baseline is a report, never a reason to lose the GPU number
+                rec["cpu_baseline"] = {"value": None, "error": repr(err)}
+        if not args.no_extras:
+            try:
+                rec["extras"] = extras(device)
+            except Exception as err:
+                rec["extras"] = {"error": repr(err)}
+    if rank == 0:
+        print(json.dumps(rec), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

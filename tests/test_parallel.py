@@ -1,0 +1,106 @@
+"""world_size-2 ``gloo`` tests of the sharding helpers on the CPU (the N > 1 path of bench.py and
+``whvi_amd.parallel``)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from whvi_amd import parallel
+
+
+def test_shard_bounds_partition():
+    for n in (0, 1, 7, 128, 1000):
+        for world in (1, 2, 3, 8):
+            spans = [parallel.shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [e - b for b, e in spans]
+            assert max(sizes) - min(sizes) <= 1
+    assert len({parallel.sample_seed(0, r) for r in range(8)}) == 8
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import torch.nn as nn
+    import fwht_cpp
+    from whvi_amd.layers import WHVILinear
+    from whvi_amd.networks import WHVIRegression
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # 1. row-sharded FWHT: every rank transforms its slice, results concatenate to the full answer
+        g = torch.Generator().manual_seed(0)
+        full = torch.randn(38, 64, generator=g)   # even split: plain all_gather needs equal blocks
+        b, e = parallel.fwht_row_shard(38)
+        mine = fwht_cpp.forward(full[b:e])
+        gathered = [torch.zeros(parallel.shard_bounds(38, r, world)[1] - parallel.shard_bounds(38, r, world)[0], 64)
+                    for r in range(world)]
+        dist.all_gather(gathered, mine)
+        assert torch.equal(torch.cat(gathered), fwht_cpp.forward(full))
+
+        # 2. MC-sample sharding + predictive all-gather (ragged: 5 samples over 2 ranks)
+        torch.manual_seed(1)   # identical replicated parameters on every rank
+        net = WHVIRegression([nn.Linear(2, 8), nn.ReLU(), WHVILinear(8, 8), nn.ReLU(), nn.Linear(8, 3)])
+        x = torch.randn(6, 2, generator=g)
+        pred = parallel.mc_sharded_forward(net, x, n_samples=5, base_seed=42)
+        assert pred.shape == (6, 3, 5)
+        # every rank holds the same gathered tensor
+        ref = pred.clone()
+        dist.broadcast(ref, src=0)
+        assert torch.equal(ref, pred)
+        # and rank r's block equals what r computes alone with its seed
+        lo, hi = parallel.shard_bounds(5, rank, world)
+        with torch.random.fork_rng(devices=[]):
+            torch.manual_seed(parallel.sample_seed(42, rank))
+            own = torch.stack([net.sequential(x) for _ in range(hi - lo)], dim=2)
+        assert torch.equal(pred[:, :, lo:hi], own)
+        # different ranks drew different eps
+        assert not torch.equal(pred[:, :, 0], pred[:, :, 3])
+
+        # 3. gradient all-reduce == gradient of the mean loss over ranks
+        y = torch.randn(6, 3, generator=g)
+        torch.manual_seed(100 + rank)
+        loss = net.loss(x, y, n=60)
+        loss.backward()
+        before = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).clone()
+        parallel.all_reduce_grads(net)
+        after = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+        both = [torch.zeros_like(before) for _ in range(world)]
+        dist.all_gather(both, before)
+        assert torch.allclose(after, sum(both) / world, rtol=1e-6, atol=1e-7)
+        open(os.path.join(tmp, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world_size_2_gloo(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+
+
+def test_bench_two_ranks_gloo_cpu_plumbing(tmp_path):
+    """bench.py's N > 1 control flow (barrier, max-over-ranks, single JSON line) on 2 CPU ranks."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WHVI_BENCH_CPU_PLUMBING="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0

@@ -1,0 +1,139 @@
+"""Multi-GPU execution of the WHVI hot path: one process per GPU, ``torch.distributed`` over RCCL
+(backend ``"nccl"`` on ROCm) across the xGMI mesh; ``gloo`` on CPUs for tests.
+
+The reference is single-process; this module is additive.  What shards:
+
+* rows of a batched FWHT and Monte-Carlo samples of a WHVI network are INDEPENDENT units, so they
+  are partitioned over ranks with NO collective on the data path (``shard_bounds``,
+  ``fwht_row_shard``);
+* the only exchange is the predictive-sample reduction: every rank holds predictions for its own
+  MC samples, ``(batch, n_out, S_local)``, and one all-gather assembles ``(batch, n_out, S)`` for
+  the mean / MNLL (src/networks.py:51,112-114; src/likelihoods.py:26-28).  The blocks are small
+  (MBs at most), i.e. latency-bound: a single all-gather per forward, never one per layer.
+* training additionally averages gradients of the O(D) parameter vectors (``all_reduce_grads``).
+"""
+import os
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+__all__ = ["init_from_env", "shard_bounds", "fwht_row_shard", "gather_predictions",
+           "mc_sharded_forward", "all_reduce_grads", "sample_seed"]
+
+
+def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, torch.device]:
+    """Join the job described by RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun's contract).
+    Returns (rank, world_size, device).  Single-process runs need no environment."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    use_gpu = torch.cuda.is_available()
+    device = torch.device("cuda", local) if use_gpu else torch.device("cpu")
+    if use_gpu:
+        torch.cuda.set_device(device)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        kwargs = {}
+        if use_gpu and (backend or "nccl") == "nccl":
+            kwargs["device_id"] = device
+        dist.init_process_group(backend or ("nccl" if use_gpu else "gloo"), rank=rank, world_size=world, **kwargs)
+    return rank, world, device
+
+
+def _world() -> Tuple[int, int]:
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_bounds(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """[begin, end) of a balanced contiguous partition of n units (the first n % world ranks get
+    one extra unit).  Units are rows or MC samples."""
+    base, extra = divmod(n, world)
+    begin = rank * base + min(rank, extra)
+    return begin, begin + base + (1 if rank < extra else 0)
+
+
+def fwht_row_shard(x_full_rows: int, rank: int = None, world: int = None) -> Tuple[int, int]:
+    """Row range of the ``(rows, D)`` FWHT problem owned by this rank: rows are independent, so the
+    sharded transform is each rank calling the single-GPU kernel on its slice -- no collective."""
+    r, w = _world()
+    return shard_bounds(x_full_rows, r if rank is None else rank, w if world is None else world)
+
+
+def sample_seed(base_seed: int, rank: int) -> int:
+    """Distinct, reproducible generator seed per rank so that ranks draw different eps."""
+    return (int(base_seed) * 1_000_003 + 7919 * (rank + 1)) % (2 ** 63 - 1)
+
+
+def gather_predictions(local: torch.Tensor, counts=None) -> torch.Tensor:
+    """All-gather per-rank predictions ``(batch, n_out, S_local)`` into ``(batch, n_out, S)`` with
+    rank-major sample order.  ``counts`` (samples per rank) allows ragged shards; ranks with fewer
+    samples are padded for the collective and trimmed afterwards."""
+    rank, world = _world()
+    if world == 1:
+        return local
+    s_local = local.size(2)
+    if counts is None:
+        counts = [s_local] * world
+    s_max = max(counts)
+    send = local
+    if s_local < s_max:
+        pad = torch.zeros(*local.shape[:2], s_max - s_local, dtype=local.dtype, device=local.device)
+        send = torch.cat([local, pad], dim=2)
+    # the gathered tensor is for the predictive reduction (mean / MNLL reporting); gradients flow
+    # through each rank's LOCAL samples only and are combined by all_reduce_grads
+    send = send.detach().contiguous()
+    # rank-major concatenation along dim 0 (the layout both RCCL and gloo accept)
+    flat = torch.empty((world * send.size(0),) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+    dist.all_gather_into_tensor(flat, send)
+    buf = flat.view((world,) + tuple(send.shape))
+    parts = [buf[r, :, :, :counts[r]] for r in range(world)]
+    return torch.cat(parts, dim=2)
+
+
+def mc_sharded_forward(net, x: torch.Tensor, n_samples: int, base_seed: int = 0) -> torch.Tensor:
+    """Predictive samples of a ``WHVINetwork`` with the MC-sample axis sharded over ranks.
+
+    Every rank runs the full batch through the network for its share of the ``n_samples`` draws
+    (parameters are replicated: 4 vectors of D floats per square matrix), seeded per rank, then one
+    all-gather returns ``(batch, n_out, n_samples)`` on every rank -- the layout of
+    src/networks.py:41,50-51."""
+    rank, world = _world()
+    begin, end = shard_bounds(n_samples, rank, world)
+    counts = [shard_bounds(n_samples, r, world)[1] - shard_bounds(n_samples, r, world)[0] for r in range(world)]
+    devices = [x.device] if x.device.type == "cuda" else []
+    with torch.random.fork_rng(devices=devices):
+        torch.manual_seed(sample_seed(base_seed, rank))
+        draws = []
+        for _ in range(end - begin):
+            out = net.sequential(x)
+            draws.append(out.reshape(x.size(0), out.size(-1)))
+    if draws:
+        local = torch.stack(draws, dim=2)
+    else:
+        n_out = net.sequential(x).size(-1)
+        local = torch.zeros(x.size(0), n_out, 0, dtype=x.dtype, device=x.device)
+    return gather_predictions(local, counts)
+
+
+def all_reduce_grads(module: torch.nn.Module, average: bool = True) -> None:
+    """Sum (or average) parameter gradients over ranks in ONE flattened all-reduce -- the WHVI
+    parameters are a handful of length-D vectors, so bucketing per tensor would be latency-bound."""
+    rank, world = _world()
+    if world == 1:
+        return
+    grads = [p.grad for p in module.parameters() if p.grad is not None]
+    if not grads:
+        return
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    if average:
+        flat /= world
+    offset = 0
+    for g in grads:
+        n = g.numel()
+        g.copy_(flat[offset:offset + n].view_as(g))
+        offset += n
