@@ -73,11 +73,14 @@ int whvi_fwht_bf16(void *dst, const void *src, int64_t rows, int32_t log2d, void
 int whvi_fwht_i32 (void *dst, const void *src, int64_t rows, int32_t log2d, void *stream);
 
 /* Same transform with an explicit kernel variant, for tuning and for cross-checking the
- * cross-lane code paths against each other on hardware:
- *   variant bit 0: 0 = DPP / v_permlane*_swap butterflies, 1 = ds_bpermute (__shfl_xor) only
- *   variant bit 1: 0 = software-prefetch the next tile into registers, 1 = no prefetch
- *   variant bit 2: 0 = plain loads/stores, 1 = non-temporal loads/stores
- *   variant bits 8..: blocks per CU for the persistent grid (0 = default)
+ * cross-lane code paths against each other on hardware.  variant == 0 is the production launch
+ * (what whvi_fwht_<dtype> does); otherwise
+ *   bit 0     : 1 = every cross-lane stage through ds_bpermute (__shfl_xor) instead of DPP/permlane
+ *   bit 1     : 0 = persistent loop with register prefetch of the next tile, 1 = one tile per wave
+ *   bit 2     : 1 = non-temporal loads/stores
+ *   bits 4..5 : threads per block, 0 = 256, 1 = 512, 2 = 1024 (no-prefetch variants only)
+ *   bits 8..19: cap of the grid in blocks per CU (0 = uncapped)
+ * Tuning variants beyond bit 0 exist for f32 and D = 512..4096 only; elsewhere they are ignored.
  */
 int whvi_fwht_ex(void *dst, const void *src, int64_t rows, int32_t log2d,
                  int32_t dtype, int32_t variant, void *stream);

@@ -129,3 +129,23 @@ def test_involution_and_linearity_full_size(hip_lib):
     # spot-check 64 rows against the oracle
     idx = torch.arange(0, rows, rows // 64)
     assert torch.equal(fx[idx.to(DEV)].cpu(), _oracle(x[idx.to(DEV)].cpu()))
+
+
+@pytest.mark.parametrize("dtype,log2d,rows", [(torch.float32, 10, 40000), (torch.float16, 12, 12000),
+                                              (torch.float64, 11, 9000), (torch.int32, 9, 70001)])
+def test_production_launch_geometries(dtype, log2d, rows, hip_lib):
+    """Mid-size problems take the 1024-thread-block launch with cached accesses (>= 32 tiles per CU
+    but < 256 MiB), incl. a partial last tile / partial last block; spot-check rows against the
+    oracle and the whole tensor through H.H = D.I on small integers."""
+    d = 1 << log2d
+    g = torch.Generator(device=DEV).manual_seed(5)
+    xi = torch.randint(-3, 4, (rows, d), generator=g, device=DEV, dtype=torch.int32)
+    x = xi.to(dtype)
+    fx = _hip.fwht_rows(x)
+    back = _hip.fwht_rows(fx)
+    if dtype == torch.float16:      # |FWHT| can exceed fp16 range only for huge rows; here max 3*4096 < 65504
+        assert torch.equal(fx.float(), _hip.fwht_rows(x.float()))
+    else:
+        assert torch.equal(back, x * d)
+    idx = torch.tensor([0, 1, rows // 2, rows - 2, rows - 1], device=DEV)
+    assert torch.equal(fx[idx].cpu().view(torch.uint8), _oracle(x[idx].cpu()).view(torch.uint8))

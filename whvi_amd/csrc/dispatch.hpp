@@ -21,12 +21,14 @@ template <typename T> constexpr int max_log2d()
 }
 
 // K = 16-byte chunks per lane: the smallest power of two that holds one row, but never below
-// the streaming size (64 lanes * 16 chunks * 16 B = 16 KiB of loads in flight per wave).
+// the streaming size -- as many chunks as keep the tile at 64 data VGPRs (f32/i32/f64: 16 chunks =
+// 16 KiB per wave, f16/bf16: 8 chunks = 8 KiB), so the tile still fits a 1024-thread block.
 template <typename T, int LOG2D> constexpr int pick_k()
 {
     constexpr int LV = ilog2(Elem<T>::VEC);
     constexpr int need = (LOG2D > LV + 6) ? (1 << (LOG2D - LV - 6)) : 1;
-    constexpr int stream = 16;
+    constexpr int words = Elem<T>::VEC * (int)sizeof(typename Elem<T>::acc) / 4;   // VGPRs per chunk
+    constexpr int stream = 64 / words;
     return need > stream ? need : stream;
 }
 
@@ -59,38 +61,65 @@ inline int check_common(const void *dst, const void *src, int64_t rows, int32_t 
     return WHVI_OK;
 }
 
+// Launch geometry (measured on MI355X, tools/membench.hip + tests/gpu_probe2.py):
+// the HBM system rewards (a) one tile per wave and out -- no persistent loop, no register prefetch,
+// (b) 1024-thread blocks, so 16 waves that start together cover 256 KiB contiguous, and (c)
+// non-temporal loads/stores for streams far larger than the 256 MiB Infinity Cache.  Small problems
+// use 256-thread blocks (more CUs busy) and cached accesses (the consumer is usually next in line).
+constexpr int64_t NT_MIN_BYTES = (int64_t)256 << 20;
+
 // variant word of whvi_fwht_ex (include/whvi_hip.h): bit0 shfl, bit1 no-prefetch, bit2 non-temporal,
-// bits 8..19 blocks per CU of the persistent grid.  FULL = every variant is compiled (tuning
-// sizes); otherwise only bit0 is honoured.
+// bits 4..5 block size (0: 256, 1: 512, 2: 1024 threads), bits 8..19 blocks per CU of the grid cap
+// (0 = default: uncapped, one tile per wave), bit 31: use the tuning variant word at all.
+// FULL = the extra tuning variants are compiled (f32, D = 512..4096).
 template <typename T, int LOG2D, int K, bool FULL>
 inline void launch_rows(void *dst, const void *src, int64_t n_chunks, int variant, hipStream_t st)
 {
-    constexpr bool CAN_PREFETCH = tile_vgprs<T, K>() <= 64;
+    constexpr bool SMALL_TILE = tile_vgprs<T, K>() <= 64;   // fits 1024-thread blocks / prefetch
     const int64_t n_tiles = (n_chunks + 64 * K - 1) / (64 * K);
-    int bpc = (variant >> 8) & 0xFFF;
-    if (bpc == 0) bpc = CAN_PREFETCH ? 3 : 2;
-    const int64_t want = (n_tiles + 3) / 4;
-    const int64_t cap = (int64_t)num_cu() * bpc;
-    const unsigned grid = (unsigned)(want < cap ? want : cap);
     u32x4 *d = (u32x4 *)dst;
     const u32x4 *s = (const u32x4 *)src;
-#define WHVI_LAUNCH(POL, PF, NT)                                                                      \
-    hipLaunchKernelGGL((fwht_rows_kernel<T, LOG2D, K, POL, PF, NT>), dim3(grid), dim3(256), 0, st, d, \
-                       s, n_chunks, n_tiles)
-    if constexpr (FULL && CAN_PREFETCH) {
+    const int bpc = (variant >> 8) & 0xFFF;
+#define WHVI_LAUNCH(POL, PF, NT, BLK)                                                                  \
+    do {                                                                                               \
+        int64_t grid = (n_tiles + (BLK / 64) - 1) / (BLK / 64);                                        \
+        if (bpc > 0 && grid > (int64_t)num_cu() * bpc) grid = (int64_t)num_cu() * bpc;                 \
+        hipLaunchKernelGGL((fwht_rows_kernel<T, LOG2D, K, POL, PF, NT, BLK>), dim3((unsigned)grid),    \
+                           dim3(BLK), 0, st, d, s, n_chunks, n_tiles);                                 \
+    } while (0)
+    if (variant == 0) {   // production path
+        const bool big = n_tiles >= (int64_t)32 * num_cu();
+        const bool nt = n_chunks * 16 >= NT_MIN_BYTES;
+        if constexpr (SMALL_TILE) {
+            if (big && nt) WHVI_LAUNCH(POLICY_DPP, false, true, 1024);
+            else if (big) WHVI_LAUNCH(POLICY_DPP, false, false, 1024);
+            else WHVI_LAUNCH(POLICY_DPP, false, false, 256);
+        } else {
+            WHVI_LAUNCH(POLICY_DPP, false, false, 256);
+        }
+        return;
+    }
+    if constexpr (FULL && SMALL_TILE) {
+        const int blk = (variant >> 4) & 3;
         switch (variant & 7) {
-        case 0: WHVI_LAUNCH(POLICY_DPP, true, false); break;
-        case 1: WHVI_LAUNCH(POLICY_SHFL, true, false); break;
-        case 2: WHVI_LAUNCH(POLICY_DPP, false, false); break;
-        case 3: WHVI_LAUNCH(POLICY_SHFL, false, false); break;
-        case 4: WHVI_LAUNCH(POLICY_DPP, true, true); break;
-        case 5: WHVI_LAUNCH(POLICY_SHFL, true, true); break;
-        case 6: WHVI_LAUNCH(POLICY_DPP, false, true); break;
-        default: WHVI_LAUNCH(POLICY_SHFL, false, true); break;
+        case 0: WHVI_LAUNCH(POLICY_DPP, true, false, 256); break;
+        case 1: WHVI_LAUNCH(POLICY_SHFL, false, false, 256); break;
+        case 2:
+            if (blk == 0) WHVI_LAUNCH(POLICY_DPP, false, false, 256);
+            else if (blk == 1) WHVI_LAUNCH(POLICY_DPP, false, false, 512);
+            else WHVI_LAUNCH(POLICY_DPP, false, false, 1024);
+            break;
+        case 4: WHVI_LAUNCH(POLICY_DPP, true, true, 256); break;
+        case 6:
+            if (blk == 0) WHVI_LAUNCH(POLICY_DPP, false, true, 256);
+            else if (blk == 1) WHVI_LAUNCH(POLICY_DPP, false, true, 512);
+            else WHVI_LAUNCH(POLICY_DPP, false, true, 1024);
+            break;
+        default: WHVI_LAUNCH(POLICY_SHFL, false, false, 256); break;
         }
     } else {
-        if (variant & 1) WHVI_LAUNCH(POLICY_SHFL, CAN_PREFETCH, false);
-        else WHVI_LAUNCH(POLICY_DPP, CAN_PREFETCH, false);
+        if (variant & 1) WHVI_LAUNCH(POLICY_SHFL, false, false, 256);
+        else WHVI_LAUNCH(POLICY_DPP, false, false, 256);
     }
 #undef WHVI_LAUNCH
 }
@@ -140,18 +169,34 @@ inline void launch_fused(void *dst, const void *src, const void *a, const void *
 {
     constexpr int K = pick_k<T, LOG2D>();
     constexpr int VEC = Elem<T>::VEC;
+    constexpr bool SMALL_TILE = tile_vgprs<T, K>() <= 64;
     const int64_t n_chunks = (rows << LOG2D) / VEC;
     const int64_t n_tiles = (n_chunks + 64 * K - 1) / (64 * K);
-    const int64_t want = (n_tiles + 3) / 4;
-    const int64_t cap = (int64_t)num_cu() * (tile_vgprs<T, K>() <= 64 ? 4 : 2);
-    const unsigned grid = (unsigned)(want < cap ? want : cap);
-#define WHVI_FUSED(AX, EYE)                                                                         \
-    hipLaunchKernelGGL((fused_shs_kernel<T, LOG2D, K, AX, EYE>), dim3(grid), dim3(256), 0, st,       \
-                       (u32x4 *)dst, (const u32x4 *)src, (const T *)a, (const T *)b, (const T *)c,  \
-                       n_chunks, n_tiles, n_samples, sample_stride, group_rows)
-    if (src == nullptr) WHVI_FUSED(WHVI_AXIS_ROW, true);
-    else if (axis == WHVI_AXIS_ROW) WHVI_FUSED(WHVI_AXIS_ROW, false);
-    else WHVI_FUSED(WHVI_AXIS_COL, false);
+    const FastDiv ds = make_fastdiv((uint32_t)sample_stride), dn = make_fastdiv((uint32_t)n_samples),
+                  dg = make_fastdiv((uint32_t)group_rows);
+    const bool big = SMALL_TILE && n_tiles >= (int64_t)32 * num_cu();
+    const bool nt = big && n_chunks * 16 >= NT_MIN_BYTES;
+#define WHVI_FUSED(AX, EYE, NT, BLK)                                                                    \
+    hipLaunchKernelGGL((fused_shs_kernel<T, LOG2D, K, AX, EYE, NT, BLK>),                               \
+                       dim3((unsigned)((n_tiles + (BLK / 64) - 1) / (BLK / 64))), dim3(BLK), 0, st,     \
+                       (u32x4 *)dst, (const u32x4 *)src, (const T *)a, (const T *)b, (const T *)c,      \
+                       n_chunks, n_tiles, ds, dn, dg)
+    // the fused kernel keeps one scale vector in flight next to the tile (~150 VGPRs): 512-thread
+    // blocks (8 waves = 128 KiB contiguous) are the largest that fit without spilling
+#define WHVI_FUSED_GEOM(AX, EYE)                                    \
+    do {                                                            \
+        if constexpr (SMALL_TILE) {                                 \
+            if (nt) WHVI_FUSED(AX, EYE, true, 512);                 \
+            else if (big) WHVI_FUSED(AX, EYE, false, 512);          \
+            else WHVI_FUSED(AX, EYE, false, 256);                   \
+        } else {                                                    \
+            WHVI_FUSED(AX, EYE, false, 256);                        \
+        }                                                           \
+    } while (0)
+    if (src == nullptr) WHVI_FUSED_GEOM(WHVI_AXIS_ROW, true);
+    else if (axis == WHVI_AXIS_ROW) WHVI_FUSED_GEOM(WHVI_AXIS_ROW, false);
+    else WHVI_FUSED_GEOM(WHVI_AXIS_COL, false);
+#undef WHVI_FUSED_GEOM
 #undef WHVI_FUSED
 }
 
@@ -167,6 +212,9 @@ inline int fused_dispatch(void *dst, const void *src, const void *a, const void 
         return fail(WHVI_ERR_ARG, "whvi: bad axis%s %lld", "", axis);
     if (n_samples < 1 || sample_stride < 1 || group_rows < 1)
         return fail(WHVI_ERR_ARG, "whvi: n_samples, sample_stride and group_rows must be >= 1%s", "");
+    if (rows >= ((int64_t)1 << 32) || n_samples >= ((int64_t)1 << 32) || sample_stride >= ((int64_t)1 << 32) ||
+        group_rows >= ((int64_t)1 << 32))
+        return fail(WHVI_ERR_SIZE, "whvi: the fused pipeline indexes rows with 32 bits%s", "");
     if (log2d < LV)
         return fail(WHVI_ERR_SIZE, "whvi: the fused pipeline needs D >= %s%lld elements (one 16-byte chunk)",
                     "", (long long)Elem<T>::VEC);

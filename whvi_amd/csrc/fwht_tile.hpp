@@ -81,6 +81,11 @@ template <> struct Bits<float> {
     {
         return p + __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, v) ^ sign_mask);
     }
+    static __device__ __forceinline__ float fold_sign(float v, uint32_t sign_mask)
+    {
+        return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, v) ^ sign_mask);
+    }
+    static __device__ __forceinline__ float add_folded(float p, float, float folded, bool) { return p + folded; }
 };
 template <> struct Bits<int32_t> {
     template <int LB> static __device__ __forceinline__ int32_t partner_dpp(int32_t v)
@@ -92,6 +97,16 @@ template <> struct Bits<int32_t> {
         // wraps on overflow exactly like the reference's int tensors (unsigned arithmetic)
         uint32_t uv = (uint32_t)v, up = (uint32_t)p;
         return (int32_t)(upper ? up - uv : uv + up);
+    }
+    // two's complement: -v = (v ^ m) - m with m = all ones on the upper lane
+    static __device__ __forceinline__ int32_t fold_sign(int32_t v, uint32_t sign_mask)
+    {
+        const uint32_t m = (uint32_t)((int32_t)sign_mask >> 31);
+        return (int32_t)((((uint32_t)v) ^ m) - m);
+    }
+    static __device__ __forceinline__ int32_t add_folded(int32_t p, int32_t, int32_t folded, bool)
+    {
+        return (int32_t)((uint32_t)p + (uint32_t)folded);
     }
 };
 template <> struct Bits<double> {
@@ -107,6 +122,11 @@ template <> struct Bits<double> {
         uint64_t u = __builtin_bit_cast(uint64_t, v) ^ ((uint64_t)sign_mask << 32);
         return p + __builtin_bit_cast(double, u);
     }
+    static __device__ __forceinline__ double fold_sign(double v, uint32_t sign_mask)
+    {
+        return __builtin_bit_cast(double, __builtin_bit_cast(uint64_t, v) ^ ((uint64_t)sign_mask << 32));
+    }
+    static __device__ __forceinline__ double add_folded(double p, double, double folded, bool) { return p + folded; }
 };
 
 // v_permlane{16,32}_swap on one 32-bit register pair: afterwards
@@ -195,13 +215,30 @@ __device__ __forceinline__ void fwht_tile(A (&r)[K][VEC], const int lane)
                         r[k][c] = Bits<A>::combine(r[k][c], p, sign_mask, upper);
                     }
             } else if constexpr (LB < 4) {
+                // A DPP instruction needs two wait states after a VALU write of ANY of its VGPR
+                // operands, so "v_xor t, mask, v; v_add_f32_dpp v, v, t" back to back costs an
+                // s_nop each time.  Sign-fold a group of 8 elements first, then issue their 8
+                // DPP adds: the distance covers the hazard and the nops disappear (-13 % issue
+                // slots per tile).  sched_barrier pins the grouping against the scheduler.
+                constexpr int G = (8 / VEC) > 0 ? (8 / VEC) : 1;   // chunks per group
 #pragma unroll
-                for (int k = 0; k < K; ++k)
+                for (int k0 = 0; k0 < K; k0 += G) {
+                    A t[G][VEC];
 #pragma unroll
-                    for (int c = 0; c < VEC; ++c) {
-                        A p = Bits<A>::template partner_dpp<LB>(r[k][c]);
-                        r[k][c] = Bits<A>::combine(r[k][c], p, sign_mask, upper);
-                    }
+                    for (int g = 0; g < G; ++g)
+#pragma unroll
+                        for (int c = 0; c < VEC; ++c)
+                            if (k0 + g < K) t[g][c] = Bits<A>::fold_sign(r[k0 + g][c], sign_mask);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int g = 0; g < G; ++g)
+#pragma unroll
+                        for (int c = 0; c < VEC; ++c)
+                            if (k0 + g < K)
+                                r[k0 + g][c] = Bits<A>::add_folded(
+                                    Bits<A>::template partner_dpp<LB>(r[k0 + g][c]), r[k0 + g][c], t[g][c], upper);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             } else {
                 constexpr int W = (LB == 4) ? 16 : 32;
                 constexpr int KB = (LB == 4) ? 0 : KB5;

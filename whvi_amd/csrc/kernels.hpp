@@ -154,8 +154,8 @@ __device__ __forceinline__ void st16(u32x4 *p, const u32x4 &v)
 // dst/src: n_chunks 16-byte chunks; tile t = chunks [t*64*K, (t+1)*64*K).  Only the last tile
 // can be partial; its missing chunks belong to rows that do not exist (rows never straddle
 // tiles), so they are read as zero and never stored.
-template <typename T, int LOG2D, int K, int POLICY, bool PREFETCH, bool NT>
-__global__ void __launch_bounds__(256)
+template <typename T, int LOG2D, int K, int POLICY, bool PREFETCH, bool NT, int BLOCK = 256>
+__global__ void __launch_bounds__(BLOCK)
 fwht_rows_kernel(u32x4 *dst, const u32x4 *src, int64_t n_chunks, int64_t n_tiles)
 {
     using E = Elem<T>;
@@ -165,7 +165,7 @@ fwht_rows_kernel(u32x4 *dst, const u32x4 *src, int64_t n_chunks, int64_t n_tiles
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t wpb = blockDim.x >> 6;
+    const int64_t wpb = BLOCK / 64;
     const int64_t stride = (int64_t)gridDim.x * wpb;
     int64_t t = (int64_t)blockIdx.x * wpb + wave;
     if (t >= n_tiles) return;
@@ -184,22 +184,8 @@ fwht_rows_kernel(u32x4 *dst, const u32x4 *src, int64_t n_chunks, int64_t n_tiles
             }
         }
     };
-
-    u32x4 raw[K];
-    load_tile(t, raw);
-    for (;;) {
-        A r[K][VEC];
-#pragma unroll
-        for (int k = 0; k < K; ++k) E::unpack(raw[k], r[k]);
-
-        const int64_t tn = t + stride;
-        if constexpr (PREFETCH) {
-            if (tn < n_tiles) load_tile(tn, raw);
-        }
-
-        fwht_tile<A, VEC, K, LOG2D, POLICY>(r, lane);
-
-        const int64_t base = t * TILE;
+    auto store_tile = [&](int64_t tile, A (&r)[K][VEC]) {
+        const int64_t base = tile * TILE;
         u32x4 *q = dst + base + lane;
         if (base + TILE <= n_chunks) {
 #pragma unroll
@@ -209,10 +195,37 @@ fwht_rows_kernel(u32x4 *dst, const u32x4 *src, int64_t n_chunks, int64_t n_tiles
             for (int k = 0; k < K; ++k)
                 if (base + k * 64 + lane < n_chunks) st16<NT>(q + k * 64, E::pack(r[k]));
         }
+    };
 
-        if (tn >= n_tiles) break;
-        t = tn;
-        if constexpr (!PREFETCH) load_tile(t, raw);
+    if constexpr (!PREFETCH) {
+        // plain grid-stride form: with grid == tiles/waves this is one tile per wave and out; only
+        // one tile's worth of registers is ever live (fits a 1024-thread block at 128 VGPRs)
+        for (; t < n_tiles; t += stride) {
+            A r[K][VEC];
+            {
+                u32x4 raw[K];
+                load_tile(t, raw);
+#pragma unroll
+                for (int k = 0; k < K; ++k) E::unpack(raw[k], r[k]);
+            }
+            fwht_tile<A, VEC, K, LOG2D, POLICY>(r, lane);
+            store_tile(t, r);
+        }
+    } else {
+        // software-pipelined form: tile t+stride is in flight while tile t is butterflied
+        u32x4 raw[K];
+        load_tile(t, raw);
+        for (;;) {
+            A r[K][VEC];
+#pragma unroll
+            for (int k = 0; k < K; ++k) E::unpack(raw[k], r[k]);
+            const int64_t tn = t + stride;
+            if (tn < n_tiles) load_tile(tn, raw);
+            fwht_tile<A, VEC, K, LOG2D, POLICY>(r, lane);
+            store_tile(t, r);
+            if (tn >= n_tiles) break;
+            t = tn;
+        }
     }
 }
 
@@ -238,97 +251,135 @@ __global__ void fwht_tail_kernel(T *dst, const T *src, int64_t first_row, int64_
 }
 
 // ---- fused scale -> FWHT -> scale -> FWHT -> scale ---------------------------------------------
-// Same tile ownership as fwht_rows_kernel.  AXIS_COL: scale vectors are indexed by the column
-// (idx mod D) and fetched as 16-byte chunks in the same lane layout as the data (L1/L2 hits:
-// a and c are D elements shared by every row, b is n_samples*D).  AXIS_ROW: one scalar per row.
-// EYE: src is not read; row i of each group is c[i] * e_i (torch.diag(s2), src/weights.py:73).
-// Every multiply is its own rounding (built with -ffp-contract=off), like the reference's
-// separate matmul_diag_left kernels (src/utils.py:4-12).
-template <typename T, int LOG2D, int K, int AXIS, bool EYE>
-__global__ void __launch_bounds__(256)
+// Division by a launch-invariant 32-bit divisor as multiply-high + shifts (Granlund & Montgomery):
+// row -> (group index, sample index) costs a handful of VALU ops instead of a 64-bit division.
+struct FastDiv {
+    uint32_t d, m, s1, s2;
+    __device__ __forceinline__ uint32_t div(uint32_t n) const
+    {
+        const uint32_t t = __umulhi(m, n);
+        return (t + ((n - t) >> s1)) >> s2;
+    }
+    __device__ __forceinline__ uint32_t mod(uint32_t n) const { return n - div(n) * d; }
+};
+
+inline FastDiv make_fastdiv(uint32_t d)
+{
+    FastDiv f;
+    f.d = d;
+    uint32_t l = 0;
+    while (l < 32 && ((uint64_t)1 << l) < d) ++l;          // l = ceil(log2 d)
+    f.m = (uint32_t)((((uint64_t)1 << 32) * (((uint64_t)1 << l) - d)) / d + 1);
+    f.s1 = l < 1 ? l : 1;
+    f.s2 = l < 1 ? 0 : l - 1;
+    return f;
+}
+
+// Same tile ownership as fwht_rows_kernel (one tile per wave, no loop).  AXIS_COL: scale vectors
+// are indexed by the column (idx mod D) and fetched as 16-byte chunks in the same lane layout as
+// the data (L1/L2 hits: a and c are D elements shared by every row, b is n_samples*D).  AXIS_ROW:
+// one scalar per row.  EYE: src is not read; row i of each group is c[i] * e_i (torch.diag(s2),
+// src/weights.py:73).  Every multiply is its own rounding (built with -ffp-contract=off), like
+// the reference's separate matmul_diag_left kernels (src/utils.py:4-12).
+template <typename T, int LOG2D, int K, int AXIS, bool EYE, bool NT, int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
 fused_shs_kernel(u32x4 *dst, const u32x4 *src, const T *a, const T *b, const T *c,
-                 int64_t n_chunks, int64_t n_tiles, int64_t n_samples, int64_t sample_stride,
-                 int64_t group_rows)
+                 int64_t n_chunks, int64_t n_tiles, FastDiv by_sample_stride, FastDiv by_n_samples,
+                 FastDiv by_group_rows)
 {
     using E = Elem<T>;
     using A = typename E::acc;
     constexpr int VEC = E::VEC;
     constexpr int LV = ilog2(VEC);
     constexpr int TILE = 64 * K;
-    constexpr int64_t D = (int64_t)1 << LOG2D;
+    constexpr int SH = LOG2D - LV;           // log2(chunks per row)
+    constexpr uint32_t CPR = 1u << SH;
     static_assert(LOG2D >= LV, "fused kernel handles rows of at least one chunk");
-    constexpr int CPR = 1 << (LOG2D - LV);   // chunks per row
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t wpb = blockDim.x >> 6;
-    const int64_t stride = (int64_t)gridDim.x * wpb;
+    const int64_t t = (int64_t)blockIdx.x * (BLOCK / 64) + wave;
+    if (t >= n_tiles) return;
 
-    for (int64_t t = (int64_t)blockIdx.x * wpb + wave; t < n_tiles; t += stride) {
-        const int64_t base = t * TILE;
-        const bool full = base + TILE <= n_chunks;
-        auto chunk_ok = [&](int k) { return full || (base + k * 64 + lane < n_chunks); };
-        auto chunk_row = [&](int k) { return (base + k * 64 + lane) >> (LOG2D - LV); };
-        auto chunk_col = [&](int k) { return (int)((base + k * 64 + lane) & (CPR - 1)); };
-        // scale factors of chunk k: VEC column values (AXIS_COL) or one row scalar broadcast
-        auto scale = [&](const T *vec, int64_t vec_base, int k, A (&out)[VEC]) {
-            if constexpr (AXIS == WHVI_AXIS_COL) {
-                E::unpack(*reinterpret_cast<const u32x4 *>(vec + vec_base + (int64_t)chunk_col(k) * VEC), out);
-            } else {
-                const A v = (A)vec[vec_base + chunk_row(k) % group_rows];
+    const int64_t base = t * TILE;
+    const bool full = base + TILE <= n_chunks;
+    const uint32_t row0 = (uint32_t)(base >> SH);             // first row of the tile (wave-uniform)
+    auto chunk_ok = [&](int k) { return full || (base + k * 64 + lane < n_chunks); };
+    // rows never straddle tiles and TILE is a multiple of CPR or vice versa
+    auto chunk_row = [&](int k) -> uint32_t {
+        if constexpr (SH >= 6) return row0 + (uint32_t)((k * 64) >> SH);                 // wave-uniform
+        else return row0 + (uint32_t)((k * 64 + lane) >> SH);
+    };
+    auto chunk_col = [&](int k) -> uint32_t { return (uint32_t)(k * 64 + lane) & (CPR - 1); };
+    auto group_index = [&](uint32_t row) -> uint32_t {
+        if constexpr (EYE) return row & ((1u << LOG2D) - 1);   // group_rows == D
+        else return by_group_rows.mod(row);
+    };
+    auto sample_index = [&](uint32_t row) -> uint32_t {
+        return by_n_samples.mod(by_sample_stride.div(row));
+    };
+    // scale factors of chunk k: VEC column values (AXIS_COL) or one row scalar broadcast
+    auto scale = [&](const T *vec, uint32_t vec_base, int k, A (&out)[VEC]) {
+        if constexpr (AXIS == WHVI_AXIS_COL) {
+            E::unpack(*reinterpret_cast<const u32x4 *>(vec + (size_t)vec_base + chunk_col(k) * VEC), out);
+        } else {
+            const A v = (A)vec[(size_t)vec_base + group_index(chunk_row(k))];
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) out[e] = v;
-            }
-        };
+            for (int e = 0; e < VEC; ++e) out[e] = v;
+        }
+    };
 
-        A r[K][VEC];
-        // ---- load (or synthesise) + first scale
+    // Issue order = latency plan: data + first scale vector together; the middle scale vector is
+    // requested BEFORE the first transform and the last one before the second, so their L2 round
+    // trips hide under ~1500 butterfly instructions each instead of stalling the wave three times.
+    A r[K][VEC];
+    A sc[K][VEC];                      // the one scale vector in flight (AXIS_COL) / row scalars
+    auto fetch_scale = [&](const T *vec, bool per_sample) {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            const bool ok = chunk_ok(k);
-            if constexpr (EYE) {
-                const int64_t i = chunk_row(k) % group_rows;   // group_rows == D
-                const A cv = (c != nullptr) ? (A)c[i] : (A)1;
-#pragma unroll
-                for (int e = 0; e < VEC; ++e)
-                    r[k][e] = ((int64_t)chunk_col(k) * VEC + e == i) ? cv : (A)0;
-            } else {
-                u32x4 raw = {0u, 0u, 0u, 0u};
-                if (ok) raw = src[base + k * 64 + lane];
-                E::unpack(raw, r[k]);
-                if (c != nullptr) {
-                    A cv[VEC];
-                    scale(c, 0, k, cv);
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) r[k][e] = cv[e] * r[k][e];
-                }
-            }
+            uint32_t vec_base = 0;
+            if (per_sample)
+                vec_base = sample_index(chunk_row(k)) * (AXIS == WHVI_AXIS_COL ? (1u << LOG2D) : by_group_rows.d);
+            scale(vec, vec_base, k, sc[k]);
         }
-        fwht_tile<A, VEC, K, LOG2D, POLICY_DPP>(r, lane);
-        // ---- middle scale (per MC sample)
-        if (b != nullptr) {
+    };
+    auto apply_scale = [&]() {
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                const int64_t s = (chunk_row(k) / sample_stride) % n_samples;
-                A bv[VEC];
-                scale(b, s * (AXIS == WHVI_AXIS_COL ? D : group_rows), k, bv);
+        for (int k = 0; k < K; ++k)
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) r[k][e] = bv[e] * r[k][e];
-            }
-        }
-        fwht_tile<A, VEC, K, LOG2D, POLICY_DPP>(r, lane);
-        // ---- last scale + store
+            for (int e = 0; e < VEC; ++e) r[k][e] = sc[k][e] * r[k][e];
+    };
+
+    // ---- load (or synthesise) + first scale
+    if constexpr (EYE) {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            if (a != nullptr) {
-                A av[VEC];
-                scale(a, 0, k, av);
+            const uint32_t i = group_index(chunk_row(k));
+            const A cv = (c != nullptr) ? (A)c[i] : (A)1;
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) r[k][e] = av[e] * r[k][e];
-            }
-            if (chunk_ok(k)) dst[base + k * 64 + lane] = E::pack(r[k]);
+            for (int e = 0; e < VEC; ++e) r[k][e] = (chunk_col(k) * VEC + e == i) ? cv : (A)0;
         }
+    } else {
+        u32x4 raw[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            u32x4 z = {0u, 0u, 0u, 0u};
+            raw[k] = chunk_ok(k) ? ld16<NT>(src + base + k * 64 + lane) : z;
+        }
+        if (c != nullptr) fetch_scale(c, false);
+#pragma unroll
+        for (int k = 0; k < K; ++k) E::unpack(raw[k], r[k]);
+        if (c != nullptr) apply_scale();
     }
+    if (b != nullptr) fetch_scale(b, true);
+    fwht_tile<A, VEC, K, LOG2D, POLICY_DPP>(r, lane);
+    if (b != nullptr) apply_scale();
+    if (a != nullptr) fetch_scale(a, false);
+    fwht_tile<A, VEC, K, LOG2D, POLICY_DPP>(r, lane);
+    if (a != nullptr) apply_scale();
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+        if (chunk_ok(k)) st16<NT>(dst + base + k * 64 + lane, E::pack(r[k]));
 }
 
 }  // namespace whvi
