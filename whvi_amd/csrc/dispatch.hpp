@@ -38,6 +38,19 @@ template <typename T, int K> constexpr int tile_vgprs()
     return K * Elem<T>::VEC * (int)sizeof(typename Elem<T>::acc) / 4;
 }
 
+// Threads per block of the streaming launch.  1024 (16 waves = 256 KiB contiguous per block) is the
+// best memory geometry but caps the kernel at 128 VGPRs; instantiations that would spill at that
+// cap use 512 (tools/check_spills.py fails the build if any shipped kernel uses scratch).
+template <typename T, int LOG2D> constexpr int big_block()
+{
+    if (tile_vgprs<T, pick_k<T, LOG2D>()>() > 64) return 256;
+    if (std::is_same<T, float>::value) return (LOG2D >= 7 || LOG2D <= 2) ? 1024 : 512;
+    if (std::is_same<T, int32_t>::value) return 1024;
+    if (std::is_same<T, double>::value) return (LOG2D >= 5) ? 1024 : 512;
+    if (std::is_same<T, __hip_bfloat16>::value) return (LOG2D >= 8 || LOG2D <= 4) ? 1024 : 512;
+    return 512;   // __half: the pack/unpack temporaries do not fit 128 VGPRs
+}
+
 inline int check_common(const void *dst, const void *src, int64_t rows, int32_t log2d, int maxl,
                         size_t elem, bool src_optional = false)
 {
@@ -90,9 +103,10 @@ inline void launch_rows(void *dst, const void *src, int64_t n_chunks, int varian
     if (variant == 0) {   // production path
         const bool big = n_tiles >= (int64_t)32 * num_cu();
         const bool nt = n_chunks * 16 >= NT_MIN_BYTES;
-        if constexpr (SMALL_TILE) {
-            if (big && nt) WHVI_LAUNCH(POLICY_DPP, false, true, 1024);
-            else if (big) WHVI_LAUNCH(POLICY_DPP, false, false, 1024);
+        constexpr int BIG = big_block<T, LOG2D>();
+        if constexpr (BIG > 256) {
+            if (big && nt) WHVI_LAUNCH(POLICY_DPP, false, true, BIG);
+            else if (big) WHVI_LAUNCH(POLICY_DPP, false, false, BIG);
             else WHVI_LAUNCH(POLICY_DPP, false, false, 256);
         } else {
             WHVI_LAUNCH(POLICY_DPP, false, false, 256);

@@ -179,6 +179,26 @@ __device__ __forceinline__ void bfly(A &lo, A &hi)
     }
 }
 
+// Two independent butterflies on adjacent registers as ONE v_pk_add_f32 pair (f32 only): halves
+// the issue slots of every in-register stage.  Same IEEE adds/subs, so the bits do not change.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <typename A>
+__device__ __forceinline__ void bfly2(A &lo0, A &lo1, A &hi0, A &hi1)
+{
+    if constexpr (std::is_same<A, float>::value) {
+        f32x2 a = {lo0, lo1}, b = {hi0, hi1};
+        f32x2 s = a + b, d = a - b;
+        lo0 = s[0];
+        lo1 = s[1];
+        hi0 = d[0];
+        hi1 = d[1];
+    } else {
+        bfly(lo0, hi0);
+        bfly(lo1, hi1);
+    }
+}
+
 // One full FWHT of every 2^LOG2D-element row held in r[K][VEC] (layout above).
 template <typename A, int VEC, int K, int LOG2D, int POLICY>
 __device__ __forceinline__ void fwht_tile(A (&r)[K][VEC], const int lane)
@@ -197,10 +217,17 @@ __device__ __forceinline__ void fwht_tile(A (&r)[K][VEC], const int lane)
             // ---- in-chunk register stage ----
             constexpr int H = 1 << S;
 #pragma unroll
-            for (int k = 0; k < K; ++k)
+            for (int k = 0; k < K; ++k) {
+                if constexpr (H >= 2) {
 #pragma unroll
-                for (int c = 0; c < VEC; ++c)
-                    if ((c & H) == 0) bfly(r[k][c], r[k][c | H]);
+                    for (int c = 0; c < VEC; c += 2)
+                        if ((c & H) == 0) bfly2(r[k][c], r[k][c + 1], r[k][c | H], r[k][(c | H) + 1]);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < VEC; ++c)
+                        if ((c & H) == 0) bfly(r[k][c], r[k][c | H]);
+                }
+            }
         } else if constexpr (S < LV + 6) {
             // ---- lane stage ----
             constexpr int LB = S - LV;
@@ -248,10 +275,14 @@ __device__ __forceinline__ void fwht_tile(A (&r)[K][VEC], const int lane)
                 for (int k = 0; k < K; ++k)
                     if ((k & KH) == 0) {
 #pragma unroll
-                        for (int c = 0; c < VEC; ++c) {
+                        for (int c = 0; c < VEC; c += 2) {
                             swap_pair<W>(r[k][c], r[k | KH][c]);
-                            bfly(r[k][c], r[k | KH][c]);
-                            if constexpr (!PAIRED) swap_pair<W>(r[k][c], r[k | KH][c]);
+                            swap_pair<W>(r[k][c + 1], r[k | KH][c + 1]);
+                            bfly2(r[k][c], r[k][c + 1], r[k | KH][c], r[k | KH][c + 1]);
+                            if constexpr (!PAIRED) {
+                                swap_pair<W>(r[k][c], r[k | KH][c]);
+                                swap_pair<W>(r[k][c + 1], r[k | KH][c + 1]);
+                            }
                         }
                     }
             }
@@ -265,10 +296,13 @@ __device__ __forceinline__ void fwht_tile(A (&r)[K][VEC], const int lane)
             for (int k = 0; k < K; ++k)
                 if ((k & KH) == 0) {
 #pragma unroll
-                    for (int c = 0; c < VEC; ++c) {
-                        if constexpr (VIA16) swap_pair<16>(r[k][c], r[k | KH][c]);
-                        else if constexpr (VIA32) swap_pair<32>(r[k][c], r[k | KH][c]);
-                        bfly(r[k][c], r[k | KH][c]);
+                    for (int c = 0; c < VEC; c += 2) {
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            if constexpr (VIA16) swap_pair<16>(r[k][c + h], r[k | KH][c + h]);
+                            else if constexpr (VIA32) swap_pair<32>(r[k][c + h], r[k | KH][c + h]);
+                        }
+                        bfly2(r[k][c], r[k][c + 1], r[k | KH][c], r[k | KH][c + 1]);
                     }
                 }
         }
