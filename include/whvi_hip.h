@@ -117,6 +117,23 @@ int whvi_fused_shs_f64(void *dst, const void *src, const void *a, const void *b,
                        int64_t sample_stride, int64_t group_rows, int32_t axis,
                        void *stream);
 
+/* Same pipeline with per-sample outer scale vectors, for batches of INDEPENDENT weight matrices
+ * (the sub-matrices of WHVIStackedMatrix, src/weights.py:130-132,179-180, or several MC samples of
+ * several layers in one launch): with the flag set, a (resp. c) is indexed like b,
+ *     a[s*group_rows + i]  (axis = ROW)      a[s*D + j]  (axis = COL),
+ * i.e. every "sample" s carries its own s1 / s2 / u.  flags == 0 is whvi_fused_shs_<dtype>. */
+#define WHVI_FUSED_A_PER_SAMPLE 1
+#define WHVI_FUSED_C_PER_SAMPLE 2
+
+int whvi_fused_shs_ex_f32(void *dst, const void *src, const void *a, const void *b,
+                          const void *c, int64_t rows, int32_t log2d, int64_t n_samples,
+                          int64_t sample_stride, int64_t group_rows, int32_t axis,
+                          int32_t flags, void *stream);
+int whvi_fused_shs_ex_f64(void *dst, const void *src, const void *a, const void *b,
+                          const void *c, int64_t rows, int32_t log2d, int64_t n_samples,
+                          int64_t sample_stride, int64_t group_rows, int32_t axis,
+                          int32_t flags, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

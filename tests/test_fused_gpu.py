@@ -85,11 +85,35 @@ def test_fused_equals_two_plain_fwht_calls(hip_lib):
 
 
 def test_wbar_function_gradcheck_float64(hip_lib):
-    D, S = 8, 2
-    s1 = torch.randn(D, dtype=torch.float64, device=DEV, requires_grad=True)
-    s2 = torch.randn(D, dtype=torch.float64, device=DEV, requires_grad=True)
-    u = torch.randn(S, D, dtype=torch.float64, device=DEV, requires_grad=True)
-    assert torch.autograd.gradcheck(WBarFunction.apply, (s1, u, s2))
+    D, S, J = 8, 2, 3
+    s1 = torch.randn(J, D, dtype=torch.float64, device=DEV, requires_grad=True)
+    s2 = torch.randn(J, D, dtype=torch.float64, device=DEV, requires_grad=True)
+    u = torch.randn(J, S, D, dtype=torch.float64, device=DEV, requires_grad=True)
+    assert torch.autograd.gradcheck(lambda a, b, c: WBarFunction.apply(a, b, c, None), (s1, u, s2))
+    # first-row-only mode of the column layer
+    s1, s2, u = s1[:1].detach().requires_grad_(), s2[:1].detach().requires_grad_(), u[:1, :1].detach().requires_grad_()
+    assert torch.autograd.gradcheck(lambda a, b, c: WBarFunction.apply(a, b, c, 1), (s1, u, s2))
+    full = WBarFunction.apply(s1, u, s2, None)
+    assert torch.equal(WBarFunction.apply(s1, u, s2, 1), full[:, :, :1])
+
+
+def test_per_sample_outer_scales_bit_exact(hip_lib):
+    """whvi_fused_shs_ex with A/C per sample == separate launches per sample (stacked sub-matrices)."""
+    d, J = 16, 5
+    rng = np.random.default_rng(9)
+    s1, s2, u = (rng.standard_normal((J, d)).astype(np.float32) for _ in range(3))
+    got = _hip.fused_shs(None, _t(s1), _t(u), _t(s2), axis="row", n_samples=J, sample_stride=d, group_rows=d,
+                         rows=J * d, d=d, dtype=torch.float32, device=torch.device(DEV),
+                         a_per_sample=True, c_per_sample=True).cpu().numpy()
+    for j in range(J):
+        assert np.array_equal(got[j * d:(j + 1) * d], wo.w_bar(s1[j], s2[j], u[j]))
+    # column axis: every sample with its own a, b, c
+    x = rng.standard_normal((J * 3, d)).astype(np.float32)        # (sample, batch 3, D)
+    got = _hip.fused_shs(_t(x), _t(s1), _t(u), _t(s2), axis="col", n_samples=J, sample_stride=3,
+                         a_per_sample=True, c_per_sample=True).cpu().numpy()
+    for j in range(J):
+        want = oracle.pipeline(x[3 * j:3 * j + 3], s1[j], u[j][None], s2[j], n_samples=1, axis="col")
+        assert np.array_equal(got[3 * j:3 * j + 3], want)
 
 
 @pytest.mark.parametrize("name", ["sq8", "sq64b", "sq512", "sq4096", "st3x16", "st5x7b", "st13x128",

@@ -33,8 +33,14 @@ class ReplayRandn:
 
     def __call__(self, *a, **k):
         if self.i < len(self.draws):
-            t = torch.from_numpy(np.array(self.draws[self.i]))
-            self.i += 1
+            size = a[0] if len(a) == 1 and isinstance(a[0], (tuple, list, torch.Size)) else a
+            want = int(np.prod(size)) if len(size) else 1
+            first = np.array(self.draws[self.i])
+            m = max(1, want // max(1, first.size))
+            # a batched draw of shape (m, D) stands for m of the reference's sequential randn(D)
+            block = np.stack([np.array(d) for d in self.draws[self.i:self.i + m]]) if m > 1 else first
+            self.i += m
+            t = torch.from_numpy(np.ascontiguousarray(block)).reshape(tuple(size))
             dev = k.get("device", None)
             return t.to(dev) if dev is not None else t
         return self.real(*a, **k)

@@ -52,6 +52,9 @@ def _declare(lib):
         fn = getattr(lib, "whvi_fused_shs_" + sfx)
         fn.restype = ctypes.c_int
         fn.argtypes = [vp, vp, vp, vp, vp, i64, i32, i64, i64, i64, i32, vp]
+        fn = getattr(lib, "whvi_fused_shs_ex_" + sfx)
+        fn.restype = ctypes.c_int
+        fn.argtypes = [vp, vp, vp, vp, vp, i64, i32, i64, i64, i64, i32, i32, vp]
 
 
 def lib():
@@ -135,9 +138,13 @@ def fwht_rows(src: torch.Tensor, out: torch.Tensor = None, variant: int = None) 
     return out
 
 
+FUSED_A_PER_SAMPLE, FUSED_C_PER_SAMPLE = 1, 2
+
+
 def fused_shs(src, a=None, b=None, c=None, *, axis: str = "col", n_samples: int = 1,
               sample_stride: int = 1, group_rows: int = 1, rows: int = None, d: int = None,
-              dtype=None, device=None, out: torch.Tensor = None) -> torch.Tensor:
+              dtype=None, device=None, out: torch.Tensor = None, a_per_sample: bool = False,
+              c_per_sample: bool = False) -> torch.Tensor:
     """out[r] = a (.) FWHT(b_s (.) FWHT(c (.) src[r])) in ONE kernel (include/whvi_hip.h).
 
     ``src=None`` (axis="row", group_rows == d) synthesises the identity matrix per group, so
@@ -164,18 +171,19 @@ def fused_shs(src, a=None, b=None, c=None, *, axis: str = "col", n_samples: int 
             raise RuntimeError(f"fused_shs: scale vector has {v.numel()} elements, expected {n}")
         return v
 
-    if ax == AXIS_ROW:
-        a_, b_, c_ = prep(a, group_rows), prep(b, n_samples * group_rows), prep(c, group_rows)
-    else:
-        a_, b_, c_ = prep(a, d), prep(b, n_samples * d), prep(c, d)
+    unit = group_rows if ax == AXIS_ROW else d
+    a_ = prep(a, unit * (n_samples if a_per_sample else 1))
+    b_ = prep(b, unit * n_samples)
+    c_ = prep(c, unit * (n_samples if c_per_sample else 1))
+    flags = (FUSED_A_PER_SAMPLE if a_per_sample else 0) | (FUSED_C_PER_SAMPLE if c_per_sample else 0)
     if out is None:
         out = torch.empty((rows, d), dtype=dtype, device=device)
     elif not out.is_contiguous() or tuple(out.shape) != (rows, d) or out.dtype != dtype:
         raise RuntimeError("fused_shs: bad out tensor")
     ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
-    fn = getattr(lib(), "whvi_fused_shs_" + _DTYPE_SUFFIX[dtype])
+    fn = getattr(lib(), "whvi_fused_shs_ex_" + _DTYPE_SUFFIX[dtype])
     with torch.cuda.device(device):
         rc = fn(out.data_ptr(), ptr(src), ptr(a_), ptr(b_), ptr(c_), rows, log2d, n_samples,
-                sample_stride, group_rows, ax, _stream(out))
+                sample_stride, group_rows, ax, flags, _stream(out))
     _check(rc, "whvi_fused_shs")
     return out

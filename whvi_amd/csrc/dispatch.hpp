@@ -179,7 +179,7 @@ inline int fwht_dispatch(void *dst, const void *src, int64_t rows, int32_t log2d
 template <typename T, int LOG2D>
 inline void launch_fused(void *dst, const void *src, const void *a, const void *b, const void *c,
                          int64_t rows, int64_t n_samples, int64_t sample_stride, int64_t group_rows,
-                         int axis, hipStream_t st)
+                         int axis, int flags, hipStream_t st)
 {
     constexpr int K = pick_k<T, LOG2D>();
     constexpr int VEC = Elem<T>::VEC;
@@ -194,7 +194,7 @@ inline void launch_fused(void *dst, const void *src, const void *a, const void *
     hipLaunchKernelGGL((fused_shs_kernel<T, LOG2D, K, AX, EYE, NT, BLK>),                               \
                        dim3((unsigned)((n_tiles + (BLK / 64) - 1) / (BLK / 64))), dim3(BLK), 0, st,     \
                        (u32x4 *)dst, (const u32x4 *)src, (const T *)a, (const T *)b, (const T *)c,      \
-                       n_chunks, n_tiles, ds, dn, dg)
+                       n_chunks, n_tiles, ds, dn, dg, flags)
     // the fused kernel keeps one scale vector in flight next to the tile (~150 VGPRs): 512-thread
     // blocks (8 waves = 128 KiB contiguous) are the largest that fit without spilling
 #define WHVI_FUSED_GEOM(AX, EYE)                                    \
@@ -217,13 +217,15 @@ inline void launch_fused(void *dst, const void *src, const void *a, const void *
 template <typename T>
 inline int fused_dispatch(void *dst, const void *src, const void *a, const void *b, const void *c,
                           int64_t rows, int32_t log2d, int64_t n_samples, int64_t sample_stride,
-                          int64_t group_rows, int32_t axis, void *stream)
+                          int64_t group_rows, int32_t axis, int32_t flags, void *stream)
 {
     constexpr int LV = ilog2(Elem<T>::VEC);
     int rc = check_common(dst, src, rows, log2d, max_log2d<T>(), sizeof(T), true);
     if (rc != WHVI_OK) return rc;
     if (axis != WHVI_AXIS_ROW && axis != WHVI_AXIS_COL)
         return fail(WHVI_ERR_ARG, "whvi: bad axis%s %lld", "", axis);
+    if (flags & ~(WHVI_FUSED_A_PER_SAMPLE | WHVI_FUSED_C_PER_SAMPLE))
+        return fail(WHVI_ERR_ARG, "whvi: unknown fused flags%s 0x%llx", "", flags);
     if (n_samples < 1 || sample_stride < 1 || group_rows < 1)
         return fail(WHVI_ERR_ARG, "whvi: n_samples, sample_stride and group_rows must be >= 1%s", "");
     if (rows >= ((int64_t)1 << 32) || n_samples >= ((int64_t)1 << 32) || sample_stride >= ((int64_t)1 << 32) ||
@@ -241,7 +243,7 @@ inline int fused_dispatch(void *dst, const void *src, const void *a, const void 
 #define WHVI_CASE(L)                                                                                     \
     case L:                                                                                              \
         if constexpr (L >= LV && L <= max_log2d<T>())                                                    \
-            launch_fused<T, L>(dst, src, a, b, c, rows, n_samples, sample_stride, group_rows, axis, st); \
+            launch_fused<T, L>(dst, src, a, b, c, rows, n_samples, sample_stride, group_rows, axis, flags, st); \
         break;
     switch (log2d) {
         WHVI_CASE(1) WHVI_CASE(2) WHVI_CASE(3) WHVI_CASE(4) WHVI_CASE(5) WHVI_CASE(6) WHVI_CASE(7)

@@ -285,8 +285,10 @@ template <typename T, int LOG2D, int K, int AXIS, bool EYE, bool NT, int BLOCK>
 __global__ void __launch_bounds__(BLOCK)
 fused_shs_kernel(u32x4 *dst, const u32x4 *src, const T *a, const T *b, const T *c,
                  int64_t n_chunks, int64_t n_tiles, FastDiv by_sample_stride, FastDiv by_n_samples,
-                 FastDiv by_group_rows)
+                 FastDiv by_group_rows, int flags)
 {
+    const bool a_per_sample = flags & WHVI_FUSED_A_PER_SAMPLE;
+    const bool c_per_sample = flags & WHVI_FUSED_C_PER_SAMPLE;
     using E = Elem<T>;
     using A = typename E::acc;
     constexpr int VEC = E::VEC;
@@ -355,7 +357,8 @@ fused_shs_kernel(u32x4 *dst, const u32x4 *src, const T *a, const T *b, const T *
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const uint32_t i = group_index(chunk_row(k));
-            const A cv = (c != nullptr) ? (A)c[i] : (A)1;
+            const uint32_t cbase = c_per_sample ? sample_index(chunk_row(k)) * by_group_rows.d : 0u;
+            const A cv = (c != nullptr) ? (A)c[(size_t)cbase + i] : (A)1;
 #pragma unroll
             for (int e = 0; e < VEC; ++e) r[k][e] = (chunk_col(k) * VEC + e == i) ? cv : (A)0;
         }
@@ -366,7 +369,7 @@ fused_shs_kernel(u32x4 *dst, const u32x4 *src, const T *a, const T *b, const T *
             u32x4 z = {0u, 0u, 0u, 0u};
             raw[k] = chunk_ok(k) ? ld16<NT>(src + base + k * 64 + lane) : z;
         }
-        if (c != nullptr) fetch_scale(c, false);
+        if (c != nullptr) fetch_scale(c, c_per_sample);
 #pragma unroll
         for (int k = 0; k < K; ++k) E::unpack(raw[k], r[k]);
         if (c != nullptr) apply_scale();
@@ -374,7 +377,7 @@ fused_shs_kernel(u32x4 *dst, const u32x4 *src, const T *a, const T *b, const T *
     if (b != nullptr) fetch_scale(b, true);
     fwht_tile<A, VEC, K, LOG2D, POLICY_DPP>(r, lane);
     if (b != nullptr) apply_scale();
-    if (a != nullptr) fetch_scale(a, false);
+    if (a != nullptr) fetch_scale(a, a_per_sample);
     fwht_tile<A, VEC, K, LOG2D, POLICY_DPP>(r, lane);
     if (a != nullptr) apply_scale();
 #pragma unroll

@@ -33,39 +33,61 @@ __all__ = ["WHVISquarePow2Matrix", "WHVIStackedMatrix", "WHVIColumnMatrix", "WBa
 
 
 class WBarFunction(torch.autograd.Function):
-    """``W[k] = diag(s1) . fwht(diag(u[k]) . fwht(diag(s2)))`` for every row ``u[k]`` of a
-    ``(S, D)`` GPU tensor, as one fused HIP launch producing ``(S, D, D)``.
+    """Batched ``w_bar``: for J independent square matrices with S ``u`` vectors each,
 
-    Forward: ``whvi_fused_shs`` with the identity input synthesised in-kernel (no HBM read),
-    row-axis scales c = s2, b = u[k], a = s1 -- multiply / butterfly order and roundings exactly
-    those of src/weights.py:73.  Backward: the adjoint chain (H is symmetric, so every FWHT's
-    adjoint is the same FWHT, src/fwht/cuda/fwht.py:14-16) written with differentiable ops."""
+        W[j, k] = diag(s1[j]) . fwht(diag(u[j, k]) . fwht(diag(s2[j])))[:rows]
+
+    as ONE fused HIP launch producing ``(J, S, rows, D)``.  ``s1, s2``: (J, D); ``u``: (J, S, D).
+    ``rows < D`` keeps only the first rows of every matrix (all that WHVIColumnMatrix uses,
+    src/weights.py:245); row i depends on ``s1[j,i], u[j,k,i], s2[j,i]`` alone.
+
+    Forward: ``whvi_fused_shs_ex`` with the identity input synthesised in-kernel (no HBM read),
+    row-axis scales c = s2, b = u, a = s1 -- multiply / butterfly order and roundings exactly those
+    of src/weights.py:73.  Backward: the adjoint chain (H is symmetric, so every FWHT's adjoint is
+    the same FWHT, src/fwht/cuda/fwht.py:14-16) written with differentiable ops."""
 
     @staticmethod
-    def forward(ctx, s1, u, s2):
+    def forward(ctx, s1, u, s2, rows):
         from whvi_amd import _hip
-        S, D = u.shape
+        J, S, D = u.shape
+        R = D if rows is None else int(rows)
         ctx.save_for_backward(s1, u, s2)
-        out = _hip.fused_shs(None, a=s1, b=u, c=s2, axis="row", n_samples=S, sample_stride=D,
-                             group_rows=D, rows=S * D, d=D, dtype=u.dtype, device=u.device)
-        return out.view(S, D, D)
+        ctx.rows = R
+        if R == D:
+            out = _hip.fused_shs(None, a=s1.repeat_interleave(S, dim=0), b=u, c=s2.repeat_interleave(S, dim=0),
+                                 axis="row", n_samples=J * S, sample_stride=D, group_rows=D, rows=J * S * D, d=D,
+                                 dtype=u.dtype, device=u.device, a_per_sample=True, c_per_sample=True)
+            return out.view(J, S, D, D)
+        # first R rows only: one launch per (j, k) would be silly -- the kernel wants whole groups of
+        # D rows, so ask for rows [0, R) of ONE group whose per-row scalars are gathered here
+        assert J * S == 1, "partial-row mode is used by the single-matrix column layer only"
+        out = _hip.fused_shs(None, a=s1[0], b=u[0, 0], c=s2[0], axis="row", n_samples=1, sample_stride=D,
+                             group_rows=D, rows=R, d=D, dtype=u.dtype, device=u.device)
+        return out.view(1, 1, R, D)
 
     @staticmethod
     def backward(ctx, grad_W):
         s1, u, s2 = ctx.saved_tensors
-        S, D = u.shape
+        J, S, D = u.shape
+        R = ctx.rows
         fw = fwht_cuda.apply
         with torch.enable_grad():
-            gW = grad_W.reshape(S * D, D)
-            t1 = fw(torch.diag(s2))                                  # fwht(diag(s2)), (D, D)
-            g2 = (s1.unsqueeze(-1) * grad_W).reshape(S * D, D)       # adjoint of the s1 scaling
-            g1 = fw(g2).view(S, D, D)                                # adjoint of the outer FWHT
-            grad_u = (g1 * t1).sum(dim=2)                            # (S, D)
-            gx = fw((u.unsqueeze(-1) * g1).reshape(S * D, D)).view(S, D, D)
-            grad_s2 = torch.diagonal(gx, dim1=1, dim2=2).sum(dim=0)  # input was diag(s2)
-            t2 = fw((u.unsqueeze(-1) * t1).reshape(S * D, D))        # pre-s1 tensor, recomputed
-            grad_s1 = (gW * t2).view(S, D, D).sum(dim=(0, 2))
-        return grad_s1, grad_u, grad_s2
+            s1r, s2r, ur = s1[:, :R], s2[:, :R], u[:, :, :R]
+            eye = torch.eye(D, dtype=u.dtype, device=u.device)[:R]                     # rows of I
+            t1 = fw((s2r.unsqueeze(-1) * eye).reshape(J * R, D)).view(J, 1, R, D)      # fwht(diag(s2))
+            g2 = s1r.view(J, 1, R, 1) * grad_W                                         # adjoint of s1 scaling
+            g1 = fw(g2.reshape(J * S * R, D)).view(J, S, R, D)                         # adjoint of outer FWHT
+            grad_u_r = (g1 * t1).sum(dim=3)                                            # (J, S, R)
+            gx = fw((ur.unsqueeze(-1) * g1).reshape(J * S * R, D)).view(J, S, R, D)
+            grad_s2_r = torch.diagonal(gx, dim1=2, dim2=3).sum(dim=1)                  # input was diag(s2)
+            t2 = fw((ur.unsqueeze(-1) * t1).reshape(J * S * R, D)).view(J, S, R, D)    # pre-s1 tensor
+            grad_s1_r = (grad_W * t2).sum(dim=(1, 3))
+            if R == D:
+                grad_s1, grad_u, grad_s2 = grad_s1_r, grad_u_r, grad_s2_r
+            else:
+                pad = (0, D - R)
+                grad_s1, grad_u, grad_s2 = (F.pad(grad_s1_r, pad), F.pad(grad_u_r, pad), F.pad(grad_s2_r, pad))
+        return grad_s1, grad_u, grad_s2, None
 
 
 class WHVISquarePow2Matrix(nn.Module):
@@ -111,10 +133,10 @@ class WHVISquarePow2Matrix(nn.Module):
         return kl_diag_normal(self.g_mu, self.g_sigma, torch.zeros(self.D, device=dev),
                               torch.ones(self.D, device=dev) * self.lambda_)
 
-    def _w_bar_stack(self, u):
-        """``w_bar`` for every row of ``u`` (S, D) -> (S, D, D)."""
+    def _w_bar_stack(self, u, rows=None):
+        """``w_bar`` for every row of ``u`` (S, D) -> (S, D, D) (first ``rows`` rows on the GPU)."""
         if u.device.type == "cuda":
-            return WBarFunction.apply(self.s1, u, self.s2)
+            return WBarFunction.apply(self.s1.unsqueeze(0), u.unsqueeze(0), self.s2.unsqueeze(0), rows)[0]
         base = self.fwht(torch.diag(self.s2))
         return torch.stack([matmul_diag_left(self.s1, self.fwht(matmul_diag_left(row, base)))
                             for row in u])
@@ -125,10 +147,13 @@ class WHVISquarePow2Matrix(nn.Module):
             return self._w_bar_stack(u.unsqueeze(0))[0]
         return matmul_diag_left(self.s1, self.fwht(matmul_diag_left(u, self.fwht(torch.diag(self.s2)))))
 
-    def sample(self):
-        """Draw W with g ~ N(g_mu, g_sigma^2) (src/weights.py:75-85)."""
+    def sample(self, rows=None):
+        """Draw W with g ~ N(g_mu, g_sigma^2) (src/weights.py:75-85).  ``rows`` (GPU only) asks
+        for the first rows of W alone -- what the column layer consumes."""
         epsilon = torch.randn(self.D, device=self.g_mu.device)
         g_tilde = self.g_mu + self.g_sigma * epsilon
+        if rows is not None and g_tilde.device.type == "cuda":
+            return self._w_bar_stack(g_tilde.unsqueeze(0), rows=rows)[0]
         return self.w_bar(g_tilde)
 
     def sample_lrt(self, h):
@@ -181,10 +206,34 @@ class WHVIStackedMatrix(nn.Module):
     def kl(self):
         return sum(weight.kl for weight in self.weight_matrices)
 
+    def _stacked_w_bar(self, parts):
+        """All sub-matrices in ONE fused launch (the reference loops over them,
+        src/weights.py:177-180: 4 FWHT launches each).  ``parts(m, eps)`` returns the list of ``u``
+        vectors of sub-matrix m; result (stack, len(parts), D, D)."""
+        dev = self.weight_matrices[0].g_mu.device
+        # one draw for every sub-matrix, in sub-matrix order like the reference's sequential draws
+        eps = torch.randn(self.stack, self.D_in, device=dev)
+        s1 = torch.stack([m.s1 for m in self.weight_matrices])
+        s2 = torch.stack([m.s2 for m in self.weight_matrices])
+        g_mu = torch.stack([m.g_mu for m in self.weight_matrices])
+        g_sigma = F.softplus(torch.stack([m.g_rho for m in self.weight_matrices]))
+        u = torch.stack(parts(g_mu, g_sigma, eps), dim=1)          # (stack, n_parts, D)
+        return WBarFunction.apply(s1, u, s2, None)
+
+    def _on_gpu(self):
+        return self.weight_matrices[0].g_mu.device.type == "cuda"
+
     def sample(self):
+        if self._on_gpu():
+            W = self._stacked_w_bar(lambda mu, sg, eps: [mu + sg * eps])
+            return W.reshape(self.stack * self.D_in, self.D_in)
         return torch.cat([weight.sample() for weight in self.weight_matrices])
 
     def sample_lrt(self, h):
+        if self._on_gpu():
+            W = self._stacked_w_bar(lambda mu, sg, eps: [mu, sg * eps])
+            W = (W[:, 0] + W[:, 1]).reshape(self.stack * self.D_in, self.D_in)   # cat over sub-matrices
+            return h @ W.T
         return torch.cat([weight.sample_lrt(h) for weight in self.weight_matrices], dim=1)
 
     def forward(self, x, use_lrt=True):
@@ -219,7 +268,11 @@ class WHVIColumnMatrix(nn.Module):
     def sample(self):
         """First ``D`` entries of the row-major flattening of a square sample
         (src/weights.py:239-248)."""
-        matrix = torch.reshape(self.weight_submodule.sample(), (-1, 1))[:self.D]
+        if self.weight_submodule.g_mu.device.type == "cuda":
+            # the first D entries of the row-major flattening lie in row 0 (D <= D_adjusted)
+            matrix = self.weight_submodule.sample(rows=1).reshape(-1, 1)[:self.D]
+        else:
+            matrix = torch.reshape(self.weight_submodule.sample(), (-1, 1))[:self.D]
         return matrix.T if self.transposed else matrix
 
     def forward(self, x):
