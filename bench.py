@@ -228,7 +228,33 @@ def extras(device):
                 acc = acc + layer(h).sum()
             return acc + layer.kl
     ms = event_ms(fwd_kl, iters=5, warm=2)
-    out["whvilinear_512_fwd_kl_32mc_b4096"] = {"ms": round(ms, 3), "ms_per_mc_sample": round(ms / 32, 4)}
+    out["whvilinear_512_fwd_kl_32mc_b4096"] = {"ms": round(ms, 3), "ms_per_mc_sample": round(ms / 32, 4),
+                                               "mode": "reference-style loop: one forward per MC sample"}
+
+    def fwd_kl_batched():
+        with torch.no_grad():
+            return layer.forward_mc(h, 32).sum() + layer.kl
+    ms = event_ms(fwd_kl_batched, iters=5, warm=2)
+    out["whvilinear_512_fwd_kl_32mc_b4096_batched"] = {"ms": round(ms, 3), "ms_per_mc_sample": round(ms / 32, 4),
+                                                       "mode": "forward_mc: one fused launch + one batched GEMM"}
+    del layer, h
+    # BASELINE config 4 (one GPU's share): WHVIRegression 3 -> 1024 -> 1024 -> 1 on a protein-sized
+    # synthetic batch (45 730 x 3), 128 MC samples over 8 GPUs = 16 per GPU, predictive forward
+    import torch.nn as nn
+    from whvi_amd.networks import WHVIRegression
+    net = WHVIRegression([WHVILinear(3, 1024), nn.ReLU(), WHVILinear(1024, 1024), nn.ReLU(), WHVILinear(1024, 1)],
+                         eval_samples=16).to(device).eval()
+    xb = torch.randn(45730, 3, device=device)
+    res = {}
+    for mode in ("batched", "loop"):
+        net.mc_mode = mode
+
+        def predict():
+            with torch.no_grad():
+                return net(xb)
+        res[mode + "_ms"] = round(event_ms(predict, iters=3, warm=1), 3)
+    res["config"] = "batch 45730 x 3, 16 MC samples (the per-GPU share of 128 over 8 GPUs), fp32, eval forward"
+    out["whviregression_3_1024_1024_1_mc16"] = res
     return out
 
 

@@ -101,9 +101,11 @@ int whvi_fwht_ex(void *dst, const void *src, int64_t rows, int32_t log2d,
  *       (matmul_diag_right, src/utils.py:15-23): A = a[j], B_s = b[s*D + j], C = c[j]
  *       for column j (group_rows is ignored).
  *   a, b, c may each be NULL (treated as all ones, the multiply is skipped).
- *   src may be NULL only with axis = WHVI_AXIS_ROW and group_rows == D: the input is then
- *       the identity matrix per group, i.e. with c = s2 it is torch.diag(s2) of
- *       src/weights.py:73 without materialising it (no HBM read at all).
+ *   src may be NULL only with axis = WHVI_AXIS_ROW and group_rows <= D: the input is then the
+ *       first group_rows rows of the D x D identity per group, i.e. with c = s2 and
+ *       group_rows = D it is torch.diag(s2) of src/weights.py:73 without materialising it (no
+ *       HBM read at all); group_rows = 1 yields row 0 only (all WHVIColumnMatrix uses,
+ *       src/weights.py:245).
  */
 #define WHVI_AXIS_ROW 0
 #define WHVI_AXIS_COL 1

@@ -13,7 +13,7 @@ from whvi_amd import _hip
 from whvi_amd.layers import WHVILinear
 from whvi_amd.weights import WBarFunction
 
-from test_host import run_layer_bundle, ReplayRandn, _bundle, _layer_from_bundle
+from test_host import run_layer_bundle, ReplayRandn, _bundle, _layer_from_bundle, loop_vs_batched
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -148,3 +148,19 @@ def test_network_on_gpu_shapes_and_finite(hip_lib):
     assert torch.isfinite(loss) and all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
     net.eval()
     assert net(x).shape == (17, 1, 3)
+
+
+def test_batched_mc_pass_equals_loop_gpu(monkeypatch, hip_lib):
+    loop_vs_batched(DEV, monkeypatch)
+
+
+def test_partial_identity_groups(hip_lib):
+    """group_rows < D with the identity input: only the first rows of every matrix are produced."""
+    d, J, R = 64, 4, 3
+    rng = np.random.default_rng(21)
+    s1, s2, u = (rng.standard_normal((J, d)).astype(np.float32) for _ in range(3))
+    got = _hip.fused_shs(None, _t(s1[:, :R]), _t(u[:, :R]), _t(s2[:, :R]), axis="row", n_samples=J, sample_stride=R,
+                         group_rows=R, rows=J * R, d=d, dtype=torch.float32, device=torch.device(DEV),
+                         a_per_sample=True, c_per_sample=True).cpu().numpy()
+    for j in range(J):
+        assert np.array_equal(got[j * R:(j + 1) * R], wo.w_bar(s1[j], s2[j], u[j])[:R])

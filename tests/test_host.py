@@ -244,3 +244,84 @@ def test_train_and_eval_loop_runs(tmp_path):
     assert (tmp_path / "epoch-0.pth").exists()
     err, mnll = net.eval_model(X, Y)
     assert np.isfinite(err) and np.isfinite(mnll)
+
+
+# ---- batched Monte-Carlo pass (F1) vs the reference-style loop ---------------------------------
+class EpsRouter:
+    """Serves ``torch.randn`` from per-layer tables ``E[D]`` of shape (S, J, D) so that the loop
+    (one draw per sample per sub-matrix) and the batched pass (one draw per layer) see the SAME eps
+    for every (layer, sample, sub-matrix).  Layers are told apart by their D."""
+
+    def __init__(self, tables, mode, real):
+        self.tables, self.mode, self.real, self.count = tables, mode, real, {}
+
+    def __call__(self, *a, **k):
+        size = tuple(a[0]) if len(a) == 1 and isinstance(a[0], (tuple, list, torch.Size)) else tuple(a)
+        D = size[-1]
+        if D not in self.tables:
+            return self.real(*a, **k)
+        E = self.tables[D]
+        n = self.count.get(D, 0)
+        self.count[D] = n + 1
+        if len(size) == 1:                                   # loop, one sub-matrix of one sample
+            s, j = divmod(n, E.shape[1])
+            out = E[s, j]
+        elif len(size) == 3:                                 # batched stacked: (J, S, D)
+            out = E.transpose(0, 1)
+        elif self.mode == "loop":                            # loop on the GPU, stacked: (J, D) of sample n
+            out = E[n]
+        else:                                                # batched square / column: (S, D)
+            out = E[:, 0]
+        assert tuple(out.shape) == size, (out.shape, size)
+        dev = k.get("device", None)
+        return out.clone().to(dev) if dev is not None else out.clone()
+
+
+def loop_vs_batched(device, monkeypatch):
+    torch.manual_seed(4)
+    S = 5
+    net = WHVIRegression([WHVILinear(3, 16, bias=True), nn.ReLU(), WHVILinear(16, 16), nn.ReLU(), nn.Linear(16, 8),
+                          nn.ReLU(), WHVILinear(8, 1, bias=True)], train_samples=S).to(device)
+    with torch.no_grad():
+        for n_, p_ in net.named_parameters():
+            if n_.endswith("g_mu") or n_.endswith("s1") or n_.endswith("s2"):
+                p_.copy_(torch.randn(p_.shape) * 0.5)
+    g = torch.Generator().manual_seed(8)
+    tables = {4: torch.randn(S, 4, 4, generator=g), 16: torch.randn(S, 1, 16, generator=g),
+              8: torch.randn(S, 1, 8, generator=g)}
+    x, y = torch.randn(9, 3, generator=g).to(device), torch.randn(9, 1, generator=g).to(device)
+    outs, grads = {}, {}
+    real = torch.randn
+    for mode in ("loop", "batched"):
+        net.mc_mode = mode
+        net.zero_grad()
+        monkeypatch.setattr(torch, "randn", EpsRouter(tables, mode, real))
+        pred = net(x)
+        monkeypatch.undo()
+        loss = net.likelihood.mnll_batch_estimate(y, pred, 90) + net.kl
+        loss.backward()
+        outs[mode] = pred.detach().cpu()
+        grads[mode] = torch.cat([p_.grad.reshape(-1) for p_ in net.parameters()]).cpu()
+    assert outs["loop"].shape == (9, 1, S)
+    scale = float(outs["loop"].abs().max())
+    assert float((outs["loop"] - outs["batched"]).abs().max()) <= 1e-5 * scale
+    gscale = float(grads["loop"].abs().max())
+    assert float((grads["loop"] - grads["batched"]).abs().max()) <= 1e-4 * gscale
+
+
+def test_batched_mc_pass_equals_loop_cpu(monkeypatch):
+    loop_vs_batched("cpu", monkeypatch)
+
+
+def test_batched_mc_pass_reference_bundle(monkeypatch):
+    """The recorded reference run (3 samples through one WHVILinear(8,8)) through the batched pass."""
+    g = np.load(os.path.join(GOLD, "network_golden.npz"))
+    net = WHVIRegression([nn.Linear(1, 8), nn.ReLU(), WHVILinear(8, 8), nn.ReLU(), nn.Linear(8, 2)],
+                         train_samples=3, eval_samples=4)
+    net.load_state_dict({k[len("state."):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("state.")})
+    net.train()
+    net.mc_mode = "batched"
+    monkeypatch.setattr(torch, "randn", ReplayRandn([g[f"eps{i}"] for i in range(int(g["n_eps"]))]))
+    pred = net(torch.from_numpy(g["x"]))
+    monkeypatch.undo()
+    assert torch.allclose(pred, torch.from_numpy(g["pred"]), rtol=1e-5, atol=1e-6)

@@ -234,8 +234,8 @@ inline int fused_dispatch(void *dst, const void *src, const void *a, const void 
     if (log2d < LV)
         return fail(WHVI_ERR_SIZE, "whvi: the fused pipeline needs D >= %s%lld elements (one 16-byte chunk)",
                     "", (long long)Elem<T>::VEC);
-    if (src == nullptr && (axis != WHVI_AXIS_ROW || group_rows != ((int64_t)1 << log2d)))
-        return fail(WHVI_ERR_ARG, "whvi: src == NULL (identity input) needs axis = ROW and group_rows == D%s", "");
+    if (src == nullptr && (axis != WHVI_AXIS_ROW || group_rows > ((int64_t)1 << log2d)))
+        return fail(WHVI_ERR_ARG, "whvi: src == NULL (identity input) needs axis = ROW and group_rows <= D%s", "");
     if (axis == WHVI_AXIS_COL && (((uintptr_t)a & 15) || ((uintptr_t)b & 15) || ((uintptr_t)c & 15)))
         return fail(WHVI_ERR_ALIGN, "whvi: column scale vectors must be 16-byte aligned%s", "");
     if (rows == 0) return WHVI_OK;

@@ -278,8 +278,8 @@ inline FastDiv make_fastdiv(uint32_t d)
 // Same tile ownership as fwht_rows_kernel (one tile per wave, no loop).  AXIS_COL: scale vectors
 // are indexed by the column (idx mod D) and fetched as 16-byte chunks in the same lane layout as
 // the data (L1/L2 hits: a and c are D elements shared by every row, b is n_samples*D).  AXIS_ROW:
-// one scalar per row.  EYE: src is not read; row i of each group is c[i] * e_i (torch.diag(s2),
-// src/weights.py:73).  Every multiply is its own rounding (built with -ffp-contract=off), like
+// one scalar per row.  EYE: src is not read; row i of each group is c[i] * e_i (the first group_rows
+// rows of torch.diag(s2), src/weights.py:73).  Every multiply is its own rounding (built with -ffp-contract=off), like
 // the reference's separate matmul_diag_left kernels (src/utils.py:4-12).
 template <typename T, int LOG2D, int K, int AXIS, bool EYE, bool NT, int BLOCK>
 __global__ void __launch_bounds__(BLOCK)
@@ -313,10 +313,7 @@ fused_shs_kernel(u32x4 *dst, const u32x4 *src, const T *a, const T *b, const T *
         else return row0 + (uint32_t)((k * 64 + lane) >> SH);
     };
     auto chunk_col = [&](int k) -> uint32_t { return (uint32_t)(k * 64 + lane) & (CPR - 1); };
-    auto group_index = [&](uint32_t row) -> uint32_t {
-        if constexpr (EYE) return row & ((1u << LOG2D) - 1);   // group_rows == D
-        else return by_group_rows.mod(row);
-    };
+    auto group_index = [&](uint32_t row) -> uint32_t { return by_group_rows.mod(row); };
     auto sample_index = [&](uint32_t row) -> uint32_t {
         return by_n_samples.mod(by_sample_stride.div(row));
     };
@@ -356,7 +353,7 @@ fused_shs_kernel(u32x4 *dst, const u32x4 *src, const T *a, const T *b, const T *
     if constexpr (EYE) {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            const uint32_t i = group_index(chunk_row(k));
+            const uint32_t i = group_index(chunk_row(k));   // row i of the identity (i < group_rows <= D)
             const uint32_t cbase = c_per_sample ? sample_index(chunk_row(k)) * by_group_rows.d : 0u;
             const A cv = (c != nullptr) ? (A)c[(size_t)cbase + i] : (A)1;
 #pragma unroll

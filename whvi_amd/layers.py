@@ -39,3 +39,8 @@ class WHVILinear(nn.Module, WHVI):
 
     def forward(self, x):
         return self.weight_submodule.forward(x)
+
+    def forward_mc(self, x, n_samples):
+        """``n_samples`` stochastic passes at once: (batch, n_in) or (n_samples, batch, n_in) ->
+        (n_samples, batch, n_out).  Used by ``WHVINetwork`` instead of its per-sample loop."""
+        return self.weight_submodule.forward_mc(x, n_samples)

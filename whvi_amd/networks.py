@@ -42,6 +42,10 @@ class WHVINetwork(nn.Module, WHVI):
         self.eval_samples = eval_samples
         self.current_mnll = 0.0
         self.current_kl = 0.0
+        # "loop": the reference's per-sample Python loop (src/networks.py:47-51), same RNG stream;
+        # "batched": every WHVI layer draws and applies all samples at once (one fused launch + one
+        # batched GEMM per layer); "auto" = batched on the GPU, loop on the host.
+        self.mc_mode = "auto"
 
     @property
     def kl(self):
@@ -53,6 +57,11 @@ class WHVINetwork(nn.Module, WHVI):
         assert x.dim() == 2, "Input shape must be (batch_size, in_dim)"
         batch_size = x.size(0)
         n_samples = self.train_samples if self.training else self.eval_samples
+        mode = self.mc_mode
+        if mode == "auto":
+            mode = "batched" if x.device.type == "cuda" else "loop"
+        if mode == "batched":
+            return self.forward_batched(x, n_samples)
         draws = []
         for _ in range(n_samples):
             out = self.sequential.forward(x)
@@ -60,6 +69,17 @@ class WHVINetwork(nn.Module, WHVI):
         predictions = torch.stack(draws, dim=2)
         assert predictions.dim() == 3
         return predictions
+
+    def forward_batched(self, x: torch.Tensor, n_samples: int) -> torch.Tensor:
+        """All Monte-Carlo samples in one pass.  Activations carry a leading sample
+        axis ``(S, batch, features)`` from the first WHVI layer on; deterministic modules broadcast
+        over it.  Same output layout as the loop: ``(batch, out_dim, n_samples)``."""
+        h = x
+        for module in self.sequential:
+            h = module.forward_mc(h, n_samples) if hasattr(module, "forward_mc") else module(h)
+        if h.dim() == 2:                      # no stochastic layer at all: identical samples
+            h = h.unsqueeze(0).expand(n_samples, *h.shape)
+        return h.permute(1, 2, 0)
 
     def loss(self, x, y, n: int, ignore_kl=False) -> torch.Tensor:
         """Negative ELBO estimate = MNLL (+ KL) (src/networks.py:56-69)."""

@@ -53,17 +53,12 @@ class WBarFunction(torch.autograd.Function):
         R = D if rows is None else int(rows)
         ctx.save_for_backward(s1, u, s2)
         ctx.rows = R
-        if R == D:
-            out = _hip.fused_shs(None, a=s1.repeat_interleave(S, dim=0), b=u, c=s2.repeat_interleave(S, dim=0),
-                                 axis="row", n_samples=J * S, sample_stride=D, group_rows=D, rows=J * S * D, d=D,
-                                 dtype=u.dtype, device=u.device, a_per_sample=True, c_per_sample=True)
-            return out.view(J, S, D, D)
-        # first R rows only: one launch per (j, k) would be silly -- the kernel wants whole groups of
-        # D rows, so ask for rows [0, R) of ONE group whose per-row scalars are gathered here
-        assert J * S == 1, "partial-row mode is used by the single-matrix column layer only"
-        out = _hip.fused_shs(None, a=s1[0], b=u[0, 0], c=s2[0], axis="row", n_samples=1, sample_stride=D,
-                             group_rows=D, rows=R, d=D, dtype=u.dtype, device=u.device)
-        return out.view(1, 1, R, D)
+        # rows of each (j, k) matrix form one group of R rows; every group carries its own s1/u/s2
+        out = _hip.fused_shs(None, a=s1[:, :R].repeat_interleave(S, dim=0), b=u[:, :, :R],
+                             c=s2[:, :R].repeat_interleave(S, dim=0), axis="row", n_samples=J * S,
+                             sample_stride=R, group_rows=R, rows=J * S * R, d=D, dtype=u.dtype,
+                             device=u.device, a_per_sample=True, c_per_sample=True)
+        return out.view(J, S, R, D)
 
     @staticmethod
     def backward(ctx, grad_W):
@@ -172,6 +167,21 @@ class WHVISquarePow2Matrix(nn.Module):
             return out + self.bias if self.bias is not None else out
         return F.linear(x, self.sample(), self.bias)
 
+    def forward_mc(self, x, n_samples):
+        """``n_samples`` independent forward passes in one go: ``x`` is ``(batch, D)``
+        (shared input) or ``(n_samples, batch, D)``; returns ``(n_samples, batch, D)``.  Sample k is
+        what ``forward`` computes with the k-th row of one ``randn(n_samples, D)`` draw: one fused
+        launch builds every sample's weight matrix, one batched GEMM applies them."""
+        eps = torch.randn(n_samples, self.D, device=self.g_mu.device)
+        u = torch.cat((self.g_mu.unsqueeze(0), self.g_sigma * eps))             # (1 + S, D)
+        if u.device.type == "cuda":
+            W = self._w_bar_stack(u)
+        else:
+            W = torch.stack([self.w_bar(row) for row in u])
+        W = W[0] + W[1:]                                                         # (S, D, D)
+        out = torch.matmul(x, W.transpose(1, 2))                                 # broadcasts a 2-D x
+        return out + self.bias if self.bias is not None else out
+
 
 class WHVIStackedMatrix(nn.Module):
     def __init__(self, n_in, n_out, lambda_=1e-5, bias=False):
@@ -236,6 +246,30 @@ class WHVIStackedMatrix(nn.Module):
             return h @ W.T
         return torch.cat([weight.sample_lrt(h) for weight in self.weight_matrices], dim=1)
 
+    def forward_mc(self, x, n_samples):
+        """Batched MC forward, see WHVISquarePow2Matrix.forward_mc; ``x``: (batch, n_in) or
+        (n_samples, batch, n_in) -> (n_samples, batch, n_out).  Sample k of sub-matrix j uses row
+        ``[j, k]`` of one ``randn(stack, n_samples, D_in)`` draw."""
+        S, J, D = n_samples, self.stack, self.D_in
+        dev = self.weight_matrices[0].g_mu.device
+        eps = torch.randn(J, S, D, device=dev)
+        s1 = torch.stack([m.s1 for m in self.weight_matrices])
+        s2 = torch.stack([m.s2 for m in self.weight_matrices])
+        g_mu = torch.stack([m.g_mu for m in self.weight_matrices])
+        g_sigma = F.softplus(torch.stack([m.g_rho for m in self.weight_matrices]))
+        u = torch.cat((g_mu.unsqueeze(1), g_sigma.unsqueeze(1) * eps), dim=1)      # (J, 1 + S, D)
+        if dev.type == "cuda":
+            W = WBarFunction.apply(s1, u, s2, None)
+        else:
+            W = torch.stack([torch.stack([m.w_bar(row) for row in u[j]]) for j, m in enumerate(self.weight_matrices)])
+        W = (W[:, :1] + W[:, 1:]).transpose(0, 1).reshape(S, J * D, D)              # (S, stack*D, D)
+        x_padded = torch.zeros((*x.size()[:-1], D), device=x.device)
+        x_padded[..., :self.n_in] = x
+        out = torch.matmul(x_padded, W.transpose(1, 2))
+        if self.bias is not None:
+            out = out + self.bias
+        return out[..., :self.n_out]
+
     def forward(self, x, use_lrt=True):
         """Zero-pad the features to D_in, multiply, drop the surplus outputs
         (src/weights.py:182-208)."""
@@ -277,3 +311,21 @@ class WHVIColumnMatrix(nn.Module):
 
     def forward(self, x):
         return F.linear(x, self.sample(), self.bias)
+
+    def forward_mc(self, x, n_samples):
+        """Batched MC forward (direct weight sampling like ``forward``); ``x``: (batch, n_in) or
+        (n_samples, batch, n_in) -> (n_samples, batch, n_out).  Only row 0 of every sampled square
+        matrix is ever built."""
+        sq = self.weight_submodule
+        eps = torch.randn(n_samples, sq.D, device=sq.g_mu.device)
+        g_tilde = sq.g_mu + sq.g_sigma * eps                                        # (S, D_adj)
+        if g_tilde.device.type == "cuda":
+            rows0 = sq._w_bar_stack(g_tilde, rows=1)[:, 0]                           # (S, D_adj)
+        else:
+            rows0 = torch.stack([sq.w_bar(g)[0] for g in g_tilde])
+        w = rows0[:, :self.D]                                                        # (S, D)
+        if self.transposed:                       # weight (1, D): out = x . w
+            out = (x * w.unsqueeze(1)).sum(dim=-1, keepdim=True)
+        else:                                     # weight (D, 1): out = x[..., :1] * w
+            out = x * w.unsqueeze(1)
+        return out + self.bias if self.bias is not None else out
