@@ -83,6 +83,54 @@ __global__ void __launch_bounds__(B) row_tile(u32x4 *buf, int64_t n_blocks)
     for (int k = 0; k < K; ++k) { c[k][0] ^= 1u; st<NT>(base + k * B, c[k]); }
 }
 
+// Cache-policy and placement experiments on the production geometry (wave = 16 KiB contiguous,
+// 1024-thread blocks, all loads -> wait -> all stores).  LD/ST: bit0 sc0, bit1 sc1, bit2 nt.
+// MAP: 0 = block b owns tiles [16b, 16b+16); 1 = XCD-contiguous (blocks that share an XCD, b % 8
+// equal, walk one contiguous eighth of the buffer); OOP: write to a second buffer.
+#define GLD(MODS) asm volatile("global_load_dwordx4 %0, %1, off" MODS : "=v"(c[k]) : "v"(p + k * 64) : "memory")
+#define GST(MODS) asm volatile("global_store_dwordx4 %0, %1, off" MODS :: "v"(q + k * 64), "v"(c[k]) : "memory")
+template <int LD, int ST, int MAP, bool OOP, int B>
+__global__ void __launch_bounds__(B) policy_tile(u32x4 *buf, u32x4 *out, int64_t n_tiles)
+{
+    constexpr int K = 16;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int64_t b = blockIdx.x;
+    if constexpr (MAP == 1) {
+        const int64_t nb = gridDim.x, per = nb / 8;
+        b = (b % 8) * per + b / 8;            // nb is a multiple of 8 in this benchmark
+    }
+    const int64_t t = b * (B / 64) + wave;
+    if (t >= n_tiles) return;
+    const u32x4 *p = buf + t * 64 * K + lane;
+    u32x4 *q = (OOP ? out : buf) + t * 64 * K + lane;
+    u32x4 c[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        if constexpr (LD == 0) GLD("");
+        else if constexpr (LD == 4) GLD(" nt");
+        else if constexpr (LD == 5) GLD(" sc0 nt");
+        else if constexpr (LD == 6) GLD(" sc1 nt");
+        else if constexpr (LD == 7) GLD(" sc0 sc1 nt");
+        else if constexpr (LD == 2) GLD(" sc1");
+        else if constexpr (LD == 1) GLD(" sc0");
+        else GLD(" sc0 sc1");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        c[k][0] ^= 1u;
+        if constexpr (ST == 0) GST("");
+        else if constexpr (ST == 4) GST(" nt");
+        else if constexpr (ST == 5) GST(" sc0 nt");
+        else if constexpr (ST == 6) GST(" sc1 nt");
+        else if constexpr (ST == 7) GST(" sc0 sc1 nt");
+        else if constexpr (ST == 2) GST(" sc1");
+        else if constexpr (ST == 1) GST(" sc0");
+        else GST(" sc0 sc1");
+    }
+}
+
 // BLOCK tiles: block of B threads owns B*K chunks, thread i chunk k*B+i (elementwise-kernel layout)
 template <int K, int B, int NT>
 __global__ void __launch_bounds__(B) block_tile(u32x4 *buf, int64_t n_tiles)
@@ -111,7 +159,13 @@ static float time_ms(void (*launch)(void *), void *ctx, int iters)
     return ms / iters;
 }
 
-struct Ctx { u32x4 *buf; int64_t chunks; int grid; int lds; };
+struct Ctx { u32x4 *buf; int64_t chunks; int grid; int lds; u32x4 *out; };
+template <int LD, int ST, int MAP, bool OOP, int B> static void l_policy(void *p)
+{
+    Ctx *c = (Ctx *)p; int64_t tiles = c->chunks / (64 * 16);
+    hipLaunchKernelGGL((policy_tile<LD, ST, MAP, OOP, B>), dim3((unsigned)(tiles / (B / 64))), dim3(B), 0, 0,
+                       c->buf, c->out, tiles);
+}
 
 template <int K, bool PF, int NT, int B = 256, bool ROT = false> static void l_wave(void *p)
 {
@@ -142,28 +196,25 @@ int main(int argc, char **argv)
     const double tb = 2.0 * bytes / 1e12;
 #define RUN(name, fn, g) do { c.grid = g; float ms = time_ms(fn, &c, 6); printf("%-44s grid %7d : %7.3f ms  %5.2f TB/s\n", name, g, ms, tb / (ms * 1e-3)); fflush(stdout); } while (0)
     c.lds = 0;
-    // 16 KiB per wave (what the register-resident D=4096 transform needs), wave-local wait
-    RUN("row K=16 B=64   wait-all", (l_row<16, 64, 3, 1>), 0);
-    RUN("row K=16 B=256  wait-all", (l_row<16, 256, 3, 1>), 0);
-    RUN("row K=16 B=1024 wait-all", (l_row<16, 1024, 3, 1>), 0);
-    RUN("row K=16 B=256  no wait", (l_row<16, 256, 3, 0>), 0);
-    // 16 KiB per 4 waves (LDS exchange between 4 waves), barrier
-    RUN("row K=4  B=256  barrier (1 row/block)", (l_row<4, 256, 3, 2>), 0);
-    RUN("row K=4  B=1024 barrier (4 rows/block)", (l_row<4, 1024, 3, 2>), 0);
-    // 16 KiB per 16 waves, barrier
-    RUN("row K=1  B=1024 barrier (1 row/block)", (l_row<1, 1024, 3, 2>), 0);
-    RUN("row K=2  B=512  barrier (1 row/block)", (l_row<2, 512, 3, 2>), 0);
-    RUN("row K=2  B=1024 barrier (2 rows/block)", (l_row<2, 1024, 3, 2>), 0);
-    RUN("row K=8  B=128  barrier (1 row/block)", (l_row<8, 128, 3, 2>), 0);
-    RUN("row K=8  B=256  barrier (2 rows/block)", (l_row<8, 256, 3, 2>), 0);
-    RUN("row K=1  B=256  barrier (4 KiB rows)", (l_row<1, 256, 3, 2>), 0);
-    RUN("row K=1  B=64   wait-all (1 KiB rows)", (l_row<1, 64, 3, 1>), 0);
-    RUN("row K=2  B=64   wait-all (2 KiB rows)", (l_row<2, 64, 3, 1>), 0);
-    RUN("row K=4  B=64   wait-all (4 KiB rows)", (l_row<4, 64, 3, 1>), 0);
-    RUN("row K=8  B=64   wait-all (8 KiB rows)", (l_row<8, 64, 3, 1>), 0);
-    // plain (no NT) versions of the main candidates
-    RUN("row K=16 B=256  wait-all plain", (l_row<16, 256, 0, 1>), 0);
-    RUN("row K=1  B=1024 barrier plain", (l_row<1, 1024, 0, 2>), 0);
-    RUN("row K=4  B=256  barrier plain", (l_row<4, 256, 0, 2>), 0);
+    CK(hipMalloc(&c.out, bytes));
+    RUN("policy ld=nt st=nt          (production)", (l_policy<4, 4, 0, false, 1024>), 0);
+    RUN("policy ld=plain st=plain", (l_policy<0, 0, 0, false, 1024>), 0);
+    RUN("policy ld=nt st=plain", (l_policy<4, 0, 0, false, 1024>), 0);
+    RUN("policy ld=plain st=nt", (l_policy<0, 4, 0, false, 1024>), 0);
+    RUN("policy ld=sc0nt st=nt", (l_policy<5, 4, 0, false, 1024>), 0);
+    RUN("policy ld=sc1nt st=nt", (l_policy<6, 4, 0, false, 1024>), 0);
+    RUN("policy ld=sc0sc1nt st=nt", (l_policy<7, 4, 0, false, 1024>), 0);
+    RUN("policy ld=nt st=sc0nt", (l_policy<4, 5, 0, false, 1024>), 0);
+    RUN("policy ld=nt st=sc1nt", (l_policy<4, 6, 0, false, 1024>), 0);
+    RUN("policy ld=nt st=sc0sc1nt", (l_policy<4, 7, 0, false, 1024>), 0);
+    RUN("policy ld=sc1 st=sc1", (l_policy<2, 2, 0, false, 1024>), 0);
+    RUN("policy ld=sc0sc1 st=sc0sc1", (l_policy<3, 3, 0, false, 1024>), 0);
+    RUN("policy ld=nt st=nt XCD-contiguous", (l_policy<4, 4, 1, false, 1024>), 0);
+    RUN("policy ld=plain st=plain XCD-contiguous", (l_policy<0, 0, 1, false, 1024>), 0);
+    RUN("policy ld=nt st=nt out-of-place", (l_policy<4, 4, 0, true, 1024>), 0);
+    RUN("policy ld=plain st=plain out-of-place", (l_policy<0, 0, 0, true, 1024>), 0);
+    RUN("policy ld=nt st=nt out-of-place XCD-contig", (l_policy<4, 4, 1, true, 1024>), 0);
+    RUN("policy ld=nt st=nt B=512", (l_policy<4, 4, 0, false, 512>), 0);
+    RUN("policy ld=nt st=nt B=512 XCD-contiguous", (l_policy<4, 4, 1, false, 512>), 0);
     return 0;
 }
