@@ -93,12 +93,14 @@ inline void launch_rows(void *dst, const void *src, int64_t n_chunks, int varian
     u32x4 *d = (u32x4 *)dst;
     const u32x4 *s = (const u32x4 *)src;
     const int bpc = (variant >> 8) & 0xFFF;
+    constexpr size_t rows_slab_bytes = (size_t)K * (64 * Elem<T>::VEC + Elem<T>::VEC) * 4;
 #define WHVI_LAUNCH(POL, PF, NT, BLK)                                                                  \
     do {                                                                                               \
         int64_t grid = (n_tiles + (BLK / 64) - 1) / (BLK / 64);                                        \
         if (bpc > 0 && grid > (int64_t)num_cu() * bpc) grid = (int64_t)num_cu() * bpc;                 \
+        const size_t smem = (POL == POLICY_LDS) ? (size_t)(BLK / 64) * rows_slab_bytes : 0;          \
         hipLaunchKernelGGL((fwht_rows_kernel<T, LOG2D, K, POL, PF, NT, BLK>), dim3((unsigned)grid),    \
-                           dim3(BLK), 0, st, d, s, n_chunks, n_tiles);                                 \
+                           dim3(BLK), smem, st, d, s, n_chunks, n_tiles);                              \
     } while (0)
     if (variant == 0) {   // production path
         const bool big = n_tiles >= (int64_t)32 * num_cu();
@@ -122,6 +124,20 @@ inline void launch_rows(void *dst, const void *src, int64_t n_chunks, int varian
             if (blk == 0) WHVI_LAUNCH(POLICY_DPP, false, false, 256);
             else if (blk == 1) WHVI_LAUNCH(POLICY_DPP, false, false, 512);
             else WHVI_LAUNCH(POLICY_DPP, false, false, 1024);
+            break;
+        case 3:
+            if constexpr (sizeof(typename Elem<T>::acc) == 4 && K * Elem<T>::VEC == 64) {
+                if (blk == 0) WHVI_LAUNCH(POLICY_LDS, false, false, 256);
+                else if (blk == 1) WHVI_LAUNCH(POLICY_LDS, false, false, 512);
+                else WHVI_LAUNCH(POLICY_LDS, false, false, 576);
+            }
+            break;
+        case 7:
+            if constexpr (sizeof(typename Elem<T>::acc) == 4 && K * Elem<T>::VEC == 64) {
+                if (blk == 0) WHVI_LAUNCH(POLICY_LDS, false, true, 256);
+                else if (blk == 1) WHVI_LAUNCH(POLICY_LDS, false, true, 512);
+                else WHVI_LAUNCH(POLICY_LDS, false, true, 576);
+            }
             break;
         case 4: WHVI_LAUNCH(POLICY_DPP, true, true, 256); break;
         case 6:
@@ -190,22 +206,47 @@ inline void launch_fused(void *dst, const void *src, const void *a, const void *
                   dg = make_fastdiv((uint32_t)group_rows);
     const bool big = SMALL_TILE && n_tiles >= (int64_t)32 * num_cu();
     const bool nt = big && n_chunks * 16 >= NT_MIN_BYTES;
-#define WHVI_FUSED(AX, EYE, NT, BLK)                                                                    \
-    hipLaunchKernelGGL((fused_shs_kernel<T, LOG2D, K, AX, EYE, NT, BLK>),                               \
-                       dim3((unsigned)((n_tiles + (BLK / 64) - 1) / (BLK / 64))), dim3(BLK), 0, st,     \
+#define WHVI_FUSED(AX, EYE, NT, BLK, POL, STG)                                                          \
+    hipLaunchKernelGGL((fused_shs_kernel<T, LOG2D, K, AX, EYE, NT, BLK, POL, STG>),                     \
+                       dim3((unsigned)((n_tiles + (BLK / 64) - 1) / (BLK / 64))), dim3(BLK),            \
+                       ((POL == POLICY_LDS) ? (size_t)(BLK / 64) * slab_bytes : 0) +                    \
+                           ((STG) ? (size_t)8 << LOG2D : 0), st,                                        \
                        (u32x4 *)dst, (const u32x4 *)src, (const T *)a, (const T *)b, (const T *)c,      \
                        n_chunks, n_tiles, ds, dn, dg, flags)
-    // the fused kernel keeps one scale vector in flight next to the tile (~150 VGPRs): 512-thread
-    // blocks (8 waves = 128 KiB contiguous) are the largest that fit without spilling
-#define WHVI_FUSED_GEOM(AX, EYE)                                    \
-    do {                                                            \
-        if constexpr (SMALL_TILE) {                                 \
-            if (nt) WHVI_FUSED(AX, EYE, true, 512);                 \
-            else if (big) WHVI_FUSED(AX, EYE, false, 512);          \
-            else WHVI_FUSED(AX, EYE, false, 256);                   \
-        } else {                                                    \
-            WHVI_FUSED(AX, EYE, false, 256);                        \
-        }                                                           \
+    constexpr bool LDS_OK = sizeof(typename Elem<T>::acc) == 4 && K * VEC == 64;
+    constexpr size_t slab_bytes = (size_t)K * (64 * VEC + VEC) * 4;   // lds_slab_floats<VEC, K>() * 4
+    // Column-axis launch of big problems, measured on MI355X (tools/tune_fused.py, D = 2048 / 4096,
+    // 4 GiB): 256-thread blocks beat 512 (12 vs 8 waves per CU at ~200 VGPRs), staging the shared a / c
+    // vectors in LDS is worth +5 %, non-temporal data accesses +4 %, and the LDS-staged butterfly
+    // network ties the DPP one (the kernel is bound by its 4x load-instruction stream, not by VALU):
+    //   dpp/256/nt/staged 5.05 TB/s | lds/256 5.00 | dpp/256 4.70 | dpp/512/nt 4.04 | lds/512/nt 4.40
+    // WHVI_FUSED_TUNE=<policy 0|2><block 2|5 (unused: always 256)><nt 0|1><stage 0|1> overrides (read once).
+    static const char *tune_env = getenv("WHVI_FUSED_TUNE");
+    const int t_pol = tune_env ? tune_env[0] - '0' : 0;
+    const int t_nt = tune_env ? tune_env[2] - '0' : (nt ? 1 : 0);
+    const int t_stg = tune_env ? tune_env[3] - '0' : 1;
+    (void)t_pol; (void)t_nt; (void)t_stg;
+#define WHVI_FUSED_GEOM(AX, EYE)                                                                        \
+    do {                                                                                                \
+        if constexpr (SMALL_TILE && AX == WHVI_AXIS_COL && !(EYE) && LDS_OK && sizeof(T) == 4 &&        \
+                      LOG2D >= 9 && LOG2D <= 12) {                                                      \
+            if (big && flags == 0) {                                                                    \
+                const int key = (t_pol == 2 ? 4 : 0) | (t_nt ? 2 : 0) | (t_stg ? 1 : 0);                \
+                switch (key) {                                                                          \
+                case 0: WHVI_FUSED(AX, EYE, false, 256, POLICY_DPP, false); break;                      \
+                case 1: WHVI_FUSED(AX, EYE, false, 256, POLICY_DPP, true); break;                       \
+                case 2: WHVI_FUSED(AX, EYE, true, 256, POLICY_DPP, false); break;                       \
+                case 3: WHVI_FUSED(AX, EYE, true, 256, POLICY_DPP, true); break;                        \
+                case 4: WHVI_FUSED(AX, EYE, false, 256, POLICY_LDS, false); break;                      \
+                case 5: WHVI_FUSED(AX, EYE, false, 256, POLICY_LDS, true); break;                       \
+                case 6: WHVI_FUSED(AX, EYE, true, 256, POLICY_LDS, false); break;                       \
+                default: WHVI_FUSED(AX, EYE, true, 256, POLICY_LDS, true); break;                       \
+                }                                                                                       \
+                break;                                                                                  \
+            }                                                                                           \
+        }                                                                                               \
+        if (nt) WHVI_FUSED(AX, EYE, true, 256, POLICY_DPP, false);                                      \
+        else WHVI_FUSED(AX, EYE, false, 256, POLICY_DPP, false);                                        \
     } while (0)
     if (src == nullptr) WHVI_FUSED_GEOM(WHVI_AXIS_ROW, true);
     else if (axis == WHVI_AXIS_ROW) WHVI_FUSED_GEOM(WHVI_AXIS_ROW, false);

@@ -37,6 +37,7 @@ namespace whvi {
 
 constexpr int POLICY_DPP = 0;
 constexpr int POLICY_SHFL = 1;
+constexpr int POLICY_LDS = 2;    // lane-bit stages through one LDS transpose (see fwht_tile_lds)
 
 constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v >> 1); }
 
@@ -306,6 +307,111 @@ __device__ __forceinline__ void fwht_tile(A (&r)[K][VEC], const int lane)
                     }
                 }
         }
+    });
+}
+
+// ---- LDS-staged variant ----------------------------------------------------------------------
+// The six lane-bit stages cost 2-3x an in-register stage on the VALU (sign fold + DPP add, or a
+// permlane swap per pair).  Here the wave transposes its tile through a private LDS slab instead:
+//
+//   layout A (as loaded):  lane l, regs (k, c):      idx = k*64*VEC + l*VEC + c
+//   layout B (transposed): lane l' = k'*VEC + c', regs j = 0..63:   idx = k'*64*VEC + j*VEC + c'
+//
+// so index bits [LV, LV+6) -- the lane id in layout A -- are REGISTER bits in layout B and all of
+// their stages are plain packed adds.  A -> B: 16-byte ds_write of each chunk (linear rows, padded
+// by one chunk), 64 ds_read_b32 at stride VEC; B -> A: the same in reverse.  Both directions are
+// conflict-free: a row pitch of 64*VEC + VEC floats puts half-wave lane l' on bank (l' + j*VEC) % 32.
+// Same adds in the same (ascending) order as the DPP network, so the bits are identical.
+// The slab is private to the wave: no block barrier, only a wavefront-scope fence so the compiler
+// keeps the write / read phases in order (the LDS processes one wave's DS operations in order).
+template <int VEC, int K> constexpr int lds_slab_floats() { return K * (64 * VEC + VEC); }
+
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <typename A, int VEC, int K, int LOG2D>
+__device__ __forceinline__ void fwht_tile_lds(A (&r)[K][VEC], const int lane, A *slab)
+{
+    static_assert(sizeof(A) == 4, "LDS-staged tile: 32-bit arithmetic types");
+    static_assert(K * VEC == 64, "layout B gives every lane one (k, c) pair");
+    constexpr int LV = ilog2(VEC);
+    constexpr int PITCH = 64 * VEC + VEC;
+    typedef A vec4 __attribute__((ext_vector_type(4)));
+
+    // stages inside a chunk (index bits < LV), layout A
+    static_for<0, (LOG2D < LV ? LOG2D : LV)>([&](auto s_) {
+        constexpr int H = 1 << decltype(s_)::value;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            if constexpr (H >= 2) {
+#pragma unroll
+                for (int c = 0; c < VEC; c += 2)
+                    if ((c & H) == 0) bfly2(r[k][c], r[k][c + 1], r[k][c | H], r[k][(c | H) + 1]);
+            } else {
+#pragma unroll
+                for (int c = 0; c < VEC; ++c)
+                    if ((c & H) == 0) bfly(r[k][c], r[k][c | H]);
+            }
+        }
+    });
+
+    if constexpr (LOG2D > LV) {
+        constexpr int NL = (LOG2D - LV) < 6 ? (LOG2D - LV) : 6;   // lane-bit stages of this row length
+        // ---- A -> B
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int c = 0; c < VEC; c += 4) {
+                vec4 v = {r[k][c], r[k][c + 1], r[k][c + 2], r[k][c + 3]};
+                *reinterpret_cast<vec4 *>(slab + k * PITCH + lane * VEC + c) = v;
+            }
+        wave_lds_fence();
+        A *col = slab + (lane / VEC) * PITCH + (lane % VEC);
+        A m[64];
+#pragma unroll
+        for (int j = 0; j < 64; ++j) m[j] = col[j * VEC];
+        // ---- the former lane stages, now in registers
+        static_for<0, NL>([&](auto b_) {
+            constexpr int H = 1 << decltype(b_)::value;
+            if constexpr (H >= 2) {
+#pragma unroll
+                for (int j = 0; j < 64; j += 2)
+                    if ((j & H) == 0) bfly2(m[j], m[j + 1], m[j | H], m[(j | H) + 1]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 64; j += 2) bfly(m[j], m[j + 1]);
+            }
+        });
+        // ---- B -> A
+#pragma unroll
+        for (int j = 0; j < 64; ++j) col[j * VEC] = m[j];
+        wave_lds_fence();
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int c = 0; c < VEC; c += 4) {
+                vec4 v = *reinterpret_cast<const vec4 *>(slab + k * PITCH + lane * VEC + c);
+                r[k][c] = v[0];
+                r[k][c + 1] = v[1];
+                r[k][c + 2] = v[2];
+                r[k][c + 3] = v[3];
+            }
+        wave_lds_fence();   // the slab may be rewritten by this wave's next transform
+    }
+
+    // stages across chunks (index bits >= LV + 6), layout A
+    static_for<LV + 6, (LOG2D > LV + 6 ? LOG2D : LV + 6)>([&](auto s_) {
+        constexpr int KH = 1 << (decltype(s_)::value - LV - 6);
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            if ((k & KH) == 0) {
+#pragma unroll
+                for (int c = 0; c < VEC; c += 2) bfly2(r[k][c], r[k][c + 1], r[k | KH][c], r[k | KH][c + 1]);
+            }
     });
 }
 

@@ -14,6 +14,7 @@
 #include <hip/hip_bf16.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/whvi_hip.h"
@@ -169,6 +170,13 @@ fwht_rows_kernel(u32x4 *dst, const u32x4 *src, int64_t n_chunks, int64_t n_tiles
     const int64_t stride = (int64_t)gridDim.x * wpb;
     int64_t t = (int64_t)blockIdx.x * wpb + wave;
     if (t >= n_tiles) return;
+    extern __shared__ __attribute__((aligned(16))) char whvi_smem[];
+    auto transform = [&](A (&r)[K][VEC]) {
+        if constexpr (POLICY == POLICY_LDS)
+            fwht_tile_lds<A, VEC, K, LOG2D>(r, lane, reinterpret_cast<A *>(whvi_smem) + wave * lds_slab_floats<VEC, K>());
+        else
+            fwht_tile<A, VEC, K, LOG2D, POLICY>(r, lane);
+    };
 
     auto load_tile = [&](int64_t tile, u32x4 (&raw)[K]) {
         const int64_t base = tile * TILE;
@@ -208,7 +216,7 @@ fwht_rows_kernel(u32x4 *dst, const u32x4 *src, int64_t n_chunks, int64_t n_tiles
 #pragma unroll
                 for (int k = 0; k < K; ++k) E::unpack(raw[k], r[k]);
             }
-            fwht_tile<A, VEC, K, LOG2D, POLICY>(r, lane);
+            transform(r);
             store_tile(t, r);
         }
     } else {
@@ -221,7 +229,7 @@ fwht_rows_kernel(u32x4 *dst, const u32x4 *src, int64_t n_chunks, int64_t n_tiles
             for (int k = 0; k < K; ++k) E::unpack(raw[k], r[k]);
             const int64_t tn = t + stride;
             if (tn < n_tiles) load_tile(tn, raw);
-            fwht_tile<A, VEC, K, LOG2D, POLICY>(r, lane);
+            transform(r);
             store_tile(t, r);
             if (tn >= n_tiles) break;
             t = tn;
@@ -281,7 +289,8 @@ inline FastDiv make_fastdiv(uint32_t d)
 // one scalar per row.  EYE: src is not read; row i of each group is c[i] * e_i (the first group_rows
 // rows of torch.diag(s2), src/weights.py:73).  Every multiply is its own rounding (built with -ffp-contract=off), like
 // the reference's separate matmul_diag_left kernels (src/utils.py:4-12).
-template <typename T, int LOG2D, int K, int AXIS, bool EYE, bool NT, int BLOCK>
+template <typename T, int LOG2D, int K, int AXIS, bool EYE, bool NT, int BLOCK, int POLICY = POLICY_DPP,
+          bool STAGE_AC = false>
 __global__ void __launch_bounds__(BLOCK)
 fused_shs_kernel(u32x4 *dst, const u32x4 *src, const T *a, const T *b, const T *c,
                  int64_t n_chunks, int64_t n_tiles, FastDiv by_sample_stride, FastDiv by_n_samples,
@@ -301,7 +310,32 @@ fused_shs_kernel(u32x4 *dst, const u32x4 *src, const T *a, const T *b, const T *
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t t = (int64_t)blockIdx.x * (BLOCK / 64) + wave;
+
+    extern __shared__ __attribute__((aligned(16))) char whvi_smem[];
+    // STAGE_AC (AXIS_COL, shared a and c): the block copies the two D-element vectors into LDS once;
+    // every wave then reads its scale chunks from there instead of issuing 2 x K more global loads
+    // through the L1 / texture path (the kernel's data stream already keeps that path busy).
+    constexpr int STAGED = STAGE_AC ? 2 * (1 << LOG2D) : 0;          // floats of LDS in front of the slabs
+    A *const lds_a = reinterpret_cast<A *>(whvi_smem);
+    A *const lds_c = lds_a + (1 << LOG2D);
+    if constexpr (STAGE_AC) {
+        static_assert(AXIS == WHVI_AXIS_COL && !EYE && sizeof(A) == 4 && sizeof(T) == 4, "staging: f32 column scales");
+        typedef A vec4 __attribute__((ext_vector_type(4)));
+        for (int i = threadIdx.x * 4; i < (1 << LOG2D); i += BLOCK * 4) {
+            if (a != nullptr) *reinterpret_cast<vec4 *>(lds_a + i) = *reinterpret_cast<const vec4 *>(a + i);
+            if (c != nullptr) *reinterpret_cast<vec4 *>(lds_c + i) = *reinterpret_cast<const vec4 *>(c + i);
+        }
+        __syncthreads();
+    }
     if (t >= n_tiles) return;
+
+    auto transform = [&](A (&r)[K][VEC]) {
+        if constexpr (POLICY == POLICY_LDS)
+            fwht_tile_lds<A, VEC, K, LOG2D>(r, lane, reinterpret_cast<A *>(whvi_smem) + STAGED +
+                                                         wave * lds_slab_floats<VEC, K>());
+        else
+            fwht_tile<A, VEC, K, LOG2D, POLICY_DPP>(r, lane);
+    };
 
     const int64_t base = t * TILE;
     const bool full = base + TILE <= n_chunks;
@@ -333,7 +367,19 @@ fused_shs_kernel(u32x4 *dst, const u32x4 *src, const T *a, const T *b, const T *
     // trips hide under ~1500 butterfly instructions each instead of stalling the wave three times.
     A r[K][VEC];
     A sc[K][VEC];                      // the one scale vector in flight (AXIS_COL) / row scalars
-    auto fetch_scale = [&](const T *vec, bool per_sample) {
+    auto fetch_scale = [&](const T *vec, bool per_sample, const A *staged = nullptr) {
+        if constexpr (STAGE_AC) {
+            if (staged != nullptr) {
+                typedef A vec4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const vec4 v = *reinterpret_cast<const vec4 *>(staged + chunk_col(k) * VEC);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) sc[k][e] = v[e];
+                }
+                return;
+            }
+        }
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             uint32_t vec_base = 0;
@@ -366,16 +412,16 @@ fused_shs_kernel(u32x4 *dst, const u32x4 *src, const T *a, const T *b, const T *
             u32x4 z = {0u, 0u, 0u, 0u};
             raw[k] = chunk_ok(k) ? ld16<NT>(src + base + k * 64 + lane) : z;
         }
-        if (c != nullptr) fetch_scale(c, c_per_sample);
+        if (c != nullptr) fetch_scale(c, c_per_sample, STAGE_AC ? lds_c : nullptr);
 #pragma unroll
         for (int k = 0; k < K; ++k) E::unpack(raw[k], r[k]);
         if (c != nullptr) apply_scale();
     }
     if (b != nullptr) fetch_scale(b, true);
-    fwht_tile<A, VEC, K, LOG2D, POLICY_DPP>(r, lane);
+    transform(r);
     if (b != nullptr) apply_scale();
-    if (a != nullptr) fetch_scale(a, a_per_sample);
-    fwht_tile<A, VEC, K, LOG2D, POLICY_DPP>(r, lane);
+    if (a != nullptr) fetch_scale(a, a_per_sample, STAGE_AC ? lds_a : nullptr);
+    transform(r);
     if (a != nullptr) apply_scale();
 #pragma unroll
     for (int k = 0; k < K; ++k)
