@@ -150,7 +150,7 @@ def recorded_traffic(workload_key):
         return None
 
 
-def cpu_baseline(log2d, target_s=12.0):
+def cpu_baseline(log2d, target_s=25.0):
     """Time the reference's C++ FWHT (or the C restatement) on a bounded sample of the workload."""
     import numpy as np
     import oracle

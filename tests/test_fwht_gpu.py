@@ -149,3 +149,41 @@ def test_production_launch_geometries(dtype, log2d, rows, hip_lib):
         assert torch.equal(back, x * d)
     idx = torch.tensor([0, 1, rows // 2, rows - 2, rows - 1], device=DEV)
     assert torch.equal(fx[idx].cpu().view(torch.uint8), _oracle(x[idx].cpu()).view(torch.uint8))
+
+
+def test_headline_size_in_place_involution(hip_lib):
+    """The bench workload itself (D = 4096, 2^20 rows = 16 GiB, > 2^32 bytes of offsets, in place,
+    non-temporal 1024-thread launch): H.H = 4096.I exactly on small integers, plus oracle rows."""
+    free, _ = torch.cuda.mem_get_info()
+    if free < 40 * 2 ** 30:
+        pytest.skip("needs ~34 GiB of free HBM")
+    d, rows = 4096, 1 << 20
+    x = torch.empty(rows, d, device=DEV)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    step = 1 << 16
+    for r in range(0, rows, step):      # fill in slabs: randint has no >2^31-element fast path guarantees
+        x[r:r + step] = torch.randint(-2, 3, (step, d), generator=g, device=DEV, dtype=torch.int32).float()
+    keep = x.clone()
+    idx = torch.tensor([0, 1, 4095, rows // 2 + 7, rows - 1], device=DEV)
+    _hip.fwht_rows(x, out=x)
+    assert torch.equal(x[idx].cpu(), _oracle(keep[idx].cpu()))
+    _hip.fwht_rows(x, out=x)
+    keep.mul_(float(d))
+    assert torch.equal(x, keep)
+
+
+def test_side_stream_and_autograd_thread(hip_lib):
+    """Launches go to torch's CURRENT stream (the reference uses the legacy default stream,
+    fwht_cuda_kernel.cu:171,177) and backward runs on the autograd engine's thread."""
+    side = torch.cuda.Stream()
+    x = _rand(257, 1024, torch.int32, 9).float().to(DEV)     # integers: H.H = D.I holds exactly
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        y = fwht_cuda.fwht(x)
+        z = fwht_cuda.fwht(y)
+    side.synchronize()
+    assert torch.equal(z, x * 1024)
+    xr = x.clone().requires_grad_(True)
+    w = torch.randn_like(x)
+    (FWHTFunction.apply(xr) * w).sum().backward()
+    assert torch.equal(xr.grad, fwht_cuda.fwht(w))       # d/dx <w, xH> = wH (H symmetric)
