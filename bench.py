@@ -255,6 +255,30 @@ def extras(device):
         res[mode + "_ms"] = round(event_ms(predict, iters=3, warm=1), 3)
     res["config"] = "batch 45730 x 3, 16 MC samples (the per-GPU share of 128 over 8 GPUs), fp32, eval forward"
     out["whviregression_3_1024_1024_1_mc16"] = res
+    del net, xb
+    # the reference's toy-regression training loop (experiments/Toy example.ipynb:319,397: 3 WHVI layers
+    # 1 -> 128 -> 128 -> 1, ~100 points, 1 MC sample, Adam, with KL: 153.17 it/s on an unnamed GPU)
+    toy = WHVIRegression([WHVILinear(1, 128), nn.ReLU(), WHVILinear(128, 128), nn.ReLU(), WHVILinear(128, 1)],
+                         train_samples=1).to(device).train()
+    tx = torch.linspace(-2, 2, 100, device=device).unsqueeze(1)
+    ty = torch.sin(3 * tx)
+    opt = torch.optim.Adam(toy.parameters(), lr=1e-3)
+
+    def train_step():
+        opt.zero_grad()
+        toy.loss(tx, ty, n=100).backward()
+        opt.step()
+    for _ in range(10):
+        train_step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(100):
+        train_step()
+    torch.cuda.synchronize()
+    out["toy_regression_training"] = {"it_per_s_with_kl": round(100 / (time.perf_counter() - t0), 1),
+                                      "reference_published_it_per_s_with_kl": 153.17,
+                                      "note": "eager PyTorch loop, launch-bound; the reference number is from "
+                                              "experiments/Toy example.ipynb on an unspecified CUDA GPU"}
     return out
 
 
