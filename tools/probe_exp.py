@@ -1,0 +1,37 @@
+"""tools/probe_exp.py -- interleaved A/B of experimental builds of the f32 FWHT kernel (whvi_amd/_exp/*.so,
+built by hand with -DWHVI_EXP_*) against the production library, same process, same buffer."""
+import ctypes, glob, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from whvi_amd import _hip
+
+x = torch.randn(1 << 20, 4096, device="cuda") * 2.0 ** -100
+libs = {"prod": _hip.lib()}
+for path in sorted(glob.glob(os.path.join(os.path.dirname(_hip.LIB_PATH), "_exp", "libexp_*.so"))):
+    L = ctypes.CDLL(path)
+    L.whvi_fwht_f32.restype = ctypes.c_int
+    L.whvi_fwht_f32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p]
+    libs[os.path.basename(path)[7:-3]] = L
+st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ms(L, iters=6):
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    L.whvi_fwht_f32(x.data_ptr(), x.data_ptr(), x.size(0), 12, st)
+    torch.cuda.synchronize()
+    s.record()
+    for _ in range(iters):
+        L.whvi_fwht_f32(x.data_ptr(), x.data_ptr(), x.size(0), 12, st)
+    e.record()
+    torch.cuda.synchronize()
+    x.mul_(0).add_(1e-30)
+    return s.elapsed_time(e) / iters
+
+
+res = {k: [] for k in libs}
+for rnd in range(5):
+    for k, L in libs.items():
+        res[k].append(ms(L))
+for k, v in res.items():
+    v.sort()
+    print(f"{k:6s} median {v[len(v)//2]:.3f} ms  min {v[0]:.3f} ms  -> {x.numel()*8/v[len(v)//2]/1e9:.2f} TB/s", flush=True)
