@@ -174,7 +174,20 @@ def cpu_baseline(log2d, target_s=25.0):
     t0 = time.perf_counter()
     run(x)
     dt = time.perf_counter() - t0
+    native = None
+    try:   # the build's own host-tensor FWHT (libwhvi_cpu.so, OpenMP over rows), same rows: the "fair" CPU number
+        import fwht_cpp
+        xs = torch.randn(1 << 15, d, generator=g)
+        fwht_cpp.forward(xs[:1024])
+        t1 = time.perf_counter()
+        fwht_cpp.forward(xs)
+        dn = time.perf_counter() - t1
+        native = {"Gtransforms_per_s": xs.size(0) / dn / 1e9, "GB_per_s_algorithmic": xs.numel() * 8 / dn / 1e9,
+                  "threads": os.cpu_count(), "sample": f"{xs.size(0)} rows of D={d} fp32, out of place"}
+    except Exception as err:
+        native = {"error": repr(err)}
     return {"value": rows / dt / 1e9, "unit": "Gtransforms/s", "cores": cores, "kind": kind,
+            "native_openmp_library": native,
             "sample": f"{rows} rows of D={d} fp32 (same row shape as the GPU workload), one call, {dt:.1f} s; "
                       + ("reference src/fwht/cpp/fwht.cpp compiled into oracle/_ref, "
                          f"{cores} torch threads of {os.cpu_count()} host CPUs" if kind == "reference"

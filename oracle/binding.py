@@ -124,25 +124,30 @@ def hadamard(n: int) -> np.ndarray:
     return (1 - 2 * par).astype(np.float64)
 
 
+_ref_module = None
+
+
 def load_reference_cpp():
-    """Return the reference's own compiled C++ FWHT module (oracle/_ref), or None."""
+    """Return the reference's own compiled C++ FWHT module (oracle/_ref), or None.
+
+    Loaded by file path under a private handle: it is NOT put on sys.path / sys.modules, so
+    ``import fwht_cpp`` elsewhere keeps resolving to the product's drop-in module."""
+    global _ref_module
+    if _ref_module is not None:
+        return _ref_module
     ref_dir = os.path.join(_HERE, "_ref")
-    if not os.path.isdir(ref_dir) or not any(f.startswith("fwht_cpp") for f in os.listdir(ref_dir)):
+    if not os.path.isdir(ref_dir):
         return None
-    import torch  # noqa: F401  (the extension links libtorch)
-    if ref_dir not in sys.path:
-        sys.path.insert(0, ref_dir)
-    try:
-        return importlib.import_module("fwht_cpp") if "fwht_cpp" not in sys.modules or \
-            getattr(sys.modules["fwht_cpp"], "__file__", "").startswith(ref_dir) else _import_from(ref_dir)
-    except ImportError:
+    paths = [os.path.join(ref_dir, f) for f in sorted(os.listdir(ref_dir)) if f.startswith("fwht_cpp") and f.endswith(".so")]
+    if not paths:
         return None
-
-
-def _import_from(ref_dir):
     import importlib.util
-    path = [os.path.join(ref_dir, f) for f in os.listdir(ref_dir) if f.startswith("fwht_cpp")][0]
-    spec = importlib.util.spec_from_file_location("fwht_cpp", path)
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
+    import torch  # noqa: F401  (the extension links libtorch)
+    try:
+        spec = importlib.util.spec_from_file_location("fwht_cpp", paths[0])
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+    except (ImportError, OSError):
+        return None
+    _ref_module = mod
     return mod
