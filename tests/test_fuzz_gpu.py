@@ -1,0 +1,104 @@
+"""Randomised GPU parity sweep: shapes the fixed tests do not enumerate (prime row counts, every launch
+geometry boundary: < 32 tiles per CU, the 1024/512-thread path, grids that are / are not multiples of 8 for
+the XCD-contiguous order, the >= 256 MiB non-temporal path) -- bit-exact against the oracle on sampled rows
+and through H.H = D.I on the whole tensor.  WHVI_FUZZ_CASES raises the case count for soak runs."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from whvi_amd import _hip
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+N_CASES = int(os.environ.get("WHVI_FUZZ_CASES", "40"))
+
+
+def _cases():
+    rng = np.random.default_rng(20260203)
+    dtypes = [torch.float32, torch.float32, torch.int32, torch.float16, torch.float64, torch.bfloat16]
+    out = []
+    for i in range(N_CASES):
+        dt = dtypes[i % len(dtypes)]
+        log2d = int(rng.integers(0, 14 if dt != torch.float64 else 13))
+        d = 1 << log2d
+        budget = int(rng.choice([1 << 14, 1 << 20, 1 << 25, 1 << 27]))          # elements
+        rows = max(1, int(budget // d * rng.uniform(0.5, 1.5)))
+        if rng.random() < 0.5:
+            rows |= 1                                                            # odd / ragged
+        out.append((i, dt, log2d, rows))
+    # one case per dtype that crosses the 256 MiB non-temporal threshold with a ragged tail
+    out += [(1000, torch.float32, 11, (1 << 15) + 13), (1001, torch.float16, 12, (1 << 15) + 7),
+            (1002, torch.int32, 3, (1 << 23) + 5)]
+    return out
+
+
+@pytest.mark.parametrize("case,dtype,log2d,rows", _cases())
+def test_random_shape(case, dtype, log2d, rows, hip_lib):
+    d = 1 << log2d
+    g = torch.Generator(device=DEV).manual_seed(case)
+    lim = 2 if dtype in (torch.float16, torch.bfloat16) else 4
+    xi = torch.randint(-lim, lim + 1, (rows, d), generator=g, device=DEV, dtype=torch.int32)
+    x = xi.to(dtype)
+    fx = _hip.fwht_rows(x)
+    # whole tensor: involution on small integers (exact in every dtype here: |fx| <= lim * D)
+    if dtype == torch.bfloat16 and lim * d > 256:
+        back = None                       # bf16 cannot hold lim*D exactly beyond 8 bits
+    else:
+        back = _hip.fwht_rows(fx)
+        assert torch.equal(back.to(torch.float64), xi.to(torch.float64) * d), (case, dtype, log2d, rows)
+    # sampled rows against the oracle, bit for bit
+    pick = torch.unique(torch.tensor([0, rows // 3, rows // 2, rows - 1]).clamp_(0, rows - 1)).to(DEV)
+    sub = x[pick].cpu()
+    if dtype in (torch.float16, torch.bfloat16):
+        want = torch.from_numpy(oracle.fwht(sub.float().numpy())).to(dtype)
+    else:
+        want = torch.from_numpy(oracle.fwht(sub.numpy()))
+    assert torch.equal(fx[pick].cpu().view(torch.uint8), want.view(torch.uint8)), (case, dtype, log2d, rows)
+    # in place == out of place
+    y = x.clone()
+    _hip.fwht_rows(y, out=y)
+    assert torch.equal(y.view(torch.uint8), fx.view(torch.uint8))
+
+
+def _fused_cases():
+    rng = np.random.default_rng(77)
+    out = []
+    for i in range(max(12, N_CASES // 2)):
+        log2d = int(rng.integers(2, 13))
+        S = int(rng.integers(1, 9))
+        axis = "col" if rng.random() < 0.6 else "row"
+        layout = int(rng.integers(0, 2))            # 0: (batch, sample, D)  1: (sample, batch, D)
+        B = int(rng.integers(1, 40))
+        big = rng.random() < 0.25
+        out.append((i, log2d, S, axis, layout, B * (400 if big else 1)))
+    return out
+
+
+@pytest.mark.parametrize("case,log2d,S,axis,layout,B", _fused_cases())
+def test_random_fused(case, log2d, S, axis, layout, B, hip_lib):
+    d = 1 << log2d
+    if B * S * d > (1 << 26):
+        B = max(1, (1 << 26) // (S * d))
+    rng = np.random.default_rng(1000 + case)
+    rows = B * S
+    x = rng.standard_normal((rows, d)).astype(np.float32)
+    stride = 1 if layout == 0 else B
+    if axis == "col":
+        a, c = rng.standard_normal(d).astype(np.float32), rng.standard_normal(d).astype(np.float32)
+        b = rng.standard_normal((S, d)).astype(np.float32)
+        kw = dict(axis="col", n_samples=S, sample_stride=stride)
+    else:
+        G = int(rng.choice([1, 3, d, 2 * d + 1]))
+        rows = (rows // G) * G or G
+        x = rng.standard_normal((rows, d)).astype(np.float32)
+        a, c = rng.standard_normal(G).astype(np.float32), rng.standard_normal(G).astype(np.float32)
+        b = rng.standard_normal((S, G)).astype(np.float32)
+        stride = G if layout == 1 else 1
+        kw = dict(axis="row", n_samples=S, sample_stride=stride, group_rows=G)
+    want = oracle.pipeline(x, a, b, c, **kw)
+    t = lambda v: torch.from_numpy(v).to(DEV)   # noqa: E731
+    got = _hip.fused_shs(t(x), t(a), t(b), t(c), **kw).cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (case, log2d, S, axis, layout, rows)

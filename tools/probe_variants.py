@@ -2,7 +2,7 @@
 its compute?  Compares, on one resident buffer, torch's in-place elementwise kernel, the FWHT kernel
 with LOG2D = 0 (same loads/stores, no butterflies) and the real transform, over variants."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # repo root
 import torch
 from whvi_amd import _hip
 

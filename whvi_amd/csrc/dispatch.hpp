@@ -74,7 +74,7 @@ inline int check_common(const void *dst, const void *src, int64_t rows, int32_t 
     return WHVI_OK;
 }
 
-// Launch geometry (measured on MI355X, tools/membench.hip + tests/gpu_probe2.py):
+// Launch geometry (measured on MI355X, tools/membench.hip + tools/probe_variants.py):
 // the HBM system rewards (a) one tile per wave and out -- no persistent loop, no register prefetch,
 // (b) 1024-thread blocks, so 16 waves that start together cover 256 KiB contiguous, and (c)
 // non-temporal loads/stores for streams far larger than the 256 MiB Infinity Cache.  Small problems
