@@ -303,7 +303,21 @@ def extras(device):
     for _ in range(100):
         train_step()
     torch.cuda.synchronize()
-    out["toy_regression_training"] = {"it_per_s_with_kl": round(100 / (time.perf_counter() - t0), 1),
+    toy_rate = round(100 / (time.perf_counter() - t0), 1)
+    # launch-bound inference: the same toy network's predictive pass (64 MC samples), eager vs hipGraph replay
+    from whvi_amd.graphs import GraphedPredictor
+    toy.eval()
+    toy.eval_samples = 64
+
+    def predict():
+        with torch.no_grad():
+            return toy.forward_batched(tx, 64)
+    eager_ms = event_ms(predict, iters=50, warm=5)
+    gp = GraphedPredictor(toy, tx, 64)
+    graph_ms = event_ms(lambda: gp(tx), iters=200, warm=5)
+    out["toy_regression_predict_64mc"] = {"eager_ms": round(eager_ms, 4), "hipgraph_replay_ms": round(graph_ms, 4)}
+    toy.train()
+    out["toy_regression_training"] = {"it_per_s_with_kl": toy_rate,
                                       "reference_published_it_per_s_with_kl": 153.17,
                                       "note": "eager PyTorch loop, launch-bound; the reference number is from "
                                               "experiments/Toy example.ipynb on an unspecified CUDA GPU"}

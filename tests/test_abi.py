@@ -48,7 +48,6 @@ def test_argument_checks_without_gpu():
     assert L.whvi_fwht_f32(None, None, 0, 3, None) == 0 and _hip.last_error() == ""   # empty batch
     assert L.whvi_fused_shs_f32(p16, p16, None, None, None, 1, 3, 0, 1, 1, 1, None) == -1  # n_samples < 1
     assert L.whvi_fused_shs_f32(p16, None, None, None, None, 1, 3, 1, 1, 9, 0, None) == -1  # identity needs group_rows <= D
-    assert L.whvi_fused_shs_f32(p16, p16, None, None, None, 1, 1, 1, 1, 1, 1, None) == -2   # D below one chunk
     assert [L.whvi_max_log2d(i) for i in range(5)] == [13, 12, 13, 13, 13] and L.whvi_max_log2d(7) == -1
 
 

@@ -164,3 +164,72 @@ def test_partial_identity_groups(hip_lib):
                          a_per_sample=True, c_per_sample=True).cpu().numpy()
     for j in range(J):
         assert np.array_equal(got[j * R:(j + 1) * R], wo.w_bar(s1[j], s2[j], u[j])[:R])
+
+
+def test_graphed_predictor_replays_fresh_samples(hip_lib):
+    """hipGraph replay of the batched predictive pass: same distribution as eager, new eps every replay,
+    and it tracks parameter updates made in place (the graph reads the live parameter tensors)."""
+    import torch.nn as nn
+    from whvi_amd.graphs import GraphedPredictor
+    from whvi_amd.networks import WHVIRegression
+    torch.manual_seed(0)
+    net = WHVIRegression([nn.Linear(2, 32), nn.Tanh(), WHVILinear(32, 32), nn.Tanh(), nn.Linear(32, 1, bias=False)],
+                         eval_samples=256).to(DEV).eval()
+    with torch.no_grad():
+        for n_, p_ in net.named_parameters():
+            if n_.endswith("s1") or n_.endswith("s2"):
+                p_.mul_(30.0)
+            if n_.endswith("g_mu"):
+                p_.add_(0.5)
+    x = torch.randn(64, 2, device=DEV)
+    gp = GraphedPredictor(net, x)
+    a = gp(x).clone()
+    b = gp(x).clone()
+    assert a.shape == (64, 1, 256) and torch.isfinite(a).all()
+    assert not torch.equal(a, b), "every replay must draw fresh eps"
+    with torch.no_grad():
+        eager = net.forward_batched(x, 256)
+    # Monte-Carlo means over 256 samples agree within sampling error (a few standard errors)
+    se = eager.std(dim=2) / 16 + 1e-6
+    assert float(((a.mean(dim=2) - eager.mean(dim=2)).abs() / se).max()) < 8.0
+    with torch.no_grad():
+        for n_, p_ in net.named_parameters():
+            if n_.endswith("g_mu"):
+                p_.zero_()
+            if n_.endswith("g_rho"):
+                p_.fill_(-30.0)       # sigma ~ 1e-13: W = 0 up to noise -> tanh(0) = 0 -> output 0
+    assert float(gp(x).abs().max()) < 1e-6
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_rows_shorter_than_a_chunk(dtype, hip_lib):
+    """D = 1, 2 (f64: D = 1) take the thread-per-row kernel: every axis / identity / per-sample combination."""
+    rng = np.random.default_rng(5)
+    for d in ((1, 2) if dtype == np.float32 else (1,)):
+        S, B = 3, 7
+        x = rng.standard_normal((B * S, d)).astype(dtype)
+        a, c = rng.standard_normal(d).astype(dtype), rng.standard_normal(d).astype(dtype)
+        b = rng.standard_normal((S, d)).astype(dtype)
+        want = oracle.pipeline(x, a, b, c, n_samples=S, sample_stride=1, axis="col")
+        got = _hip.fused_shs(_t(x), _t(a), _t(b), _t(c), axis="col", n_samples=S, sample_stride=1).cpu().numpy()
+        assert np.array_equal(_bits(got), _bits(want))
+        # identity input: what WHVILinear(2, n) / WHVILinear(1, 1) run on the GPU
+        s1, s2, u = (rng.standard_normal((S, d)).astype(dtype) for _ in range(3))
+        got = _hip.fused_shs(None, _t(s1), _t(u), _t(s2), axis="row", n_samples=S, sample_stride=d, group_rows=d,
+                             rows=S * d, d=d, dtype=torch.from_numpy(x).dtype, device=torch.device(DEV),
+                             a_per_sample=True, c_per_sample=True).cpu().numpy()
+        for k in range(S):
+            eye = np.eye(d, dtype=dtype)
+            want = oracle.pipeline(eye, s1[k], u[k][None], s2[k], n_samples=1, sample_stride=d, group_rows=d, axis="row")
+            assert np.array_equal(_bits(got[k * d:(k + 1) * d]), _bits(want))
+
+
+def test_tiny_layers_on_gpu(hip_lib):
+    """Shapes whose square blocks have D < 4: WHVILinear(2, 5) (stack of 2x2), (2, 2), (1, 1), (1, 3)."""
+    for n_in, n_out in ((2, 5), (2, 2), (1, 1), (1, 3), (3, 1), (2, 1)):
+        layer = WHVILinear(n_in, n_out, bias=True).to(DEV)
+        x = torch.randn(6, n_in, device=DEV, requires_grad=True)
+        y = layer(x)
+        (y.sum() + layer.kl).backward()
+        assert y.shape == (6, n_out) and torch.isfinite(y).all() and torch.isfinite(x.grad).all()
+        assert layer.forward_mc(x.detach(), 3).shape == (3, 6, n_out)

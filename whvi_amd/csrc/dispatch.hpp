@@ -272,15 +272,31 @@ inline int fused_dispatch(void *dst, const void *src, const void *a, const void 
     if (rows >= ((int64_t)1 << 32) || n_samples >= ((int64_t)1 << 32) || sample_stride >= ((int64_t)1 << 32) ||
         group_rows >= ((int64_t)1 << 32))
         return fail(WHVI_ERR_SIZE, "whvi: the fused pipeline indexes rows with 32 bits%s", "");
-    if (log2d < LV)
-        return fail(WHVI_ERR_SIZE, "whvi: the fused pipeline needs D >= %s%lld elements (one 16-byte chunk)",
-                    "", (long long)Elem<T>::VEC);
     if (src == nullptr && (axis != WHVI_AXIS_ROW || group_rows > ((int64_t)1 << log2d)))
         return fail(WHVI_ERR_ARG, "whvi: src == NULL (identity input) needs axis = ROW and group_rows <= D%s", "");
     if (axis == WHVI_AXIS_COL && (((uintptr_t)a & 15) || ((uintptr_t)b & 15) || ((uintptr_t)c & 15)))
         return fail(WHVI_ERR_ALIGN, "whvi: column scale vectors must be 16-byte aligned%s", "");
     if (rows == 0) return WHVI_OK;
     hipStream_t st = (hipStream_t)stream;
+    if (log2d < LV) {   // rows shorter than one chunk: thread-per-row kernel
+        const FastDiv ds = make_fastdiv((uint32_t)sample_stride), dn = make_fastdiv((uint32_t)n_samples),
+                      dg = make_fastdiv((uint32_t)group_rows);
+        const unsigned grid = (unsigned)((rows + 255) / 256);
+#define WHVI_SMALL(L, AX, EYE)                                                                             \
+    hipLaunchKernelGGL((fused_small_kernel<T, L, AX, EYE>), dim3(grid), dim3(256), 0, st, (T *)dst,        \
+                       (const T *)src, (const T *)a, (const T *)b, (const T *)c, rows, ds, dn, dg, flags)
+#define WHVI_SMALL_L(L)                                                    \
+    do {                                                                   \
+        if (src == nullptr) WHVI_SMALL(L, WHVI_AXIS_ROW, true);            \
+        else if (axis == WHVI_AXIS_ROW) WHVI_SMALL(L, WHVI_AXIS_ROW, false); \
+        else WHVI_SMALL(L, WHVI_AXIS_COL, false);                          \
+    } while (0)
+        if (log2d == 0) WHVI_SMALL_L(0);
+        else if constexpr (LV >= 2) { if (log2d == 1) WHVI_SMALL_L(1); }
+#undef WHVI_SMALL_L
+#undef WHVI_SMALL
+        return after_launch("fused_shs (short rows)");
+    }
 #define WHVI_CASE(L)                                                                                     \
     case L:                                                                                              \
         if constexpr (L >= LV && L <= max_log2d<T>())                                                    \

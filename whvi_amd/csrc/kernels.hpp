@@ -454,5 +454,52 @@ fused_shs_kernel(u32x4 *dst, const u32x4 *src, const T *a, const T *b, const T *
     }
 }
 
+// Rows shorter than one 16-byte chunk (D = 1, 2 for f32; D = 1 for f64): one thread per row, same
+// arithmetic order as the tiled kernel.  These shapes are tiny by construction (WHVILinear(2, n),
+// WHVILinear(1, 1)); they exist so that every shape the reference accepts works on the GPU too.
+template <typename T, int LOG2D, int AXIS, bool EYE>
+__global__ void fused_small_kernel(T *dst, const T *src, const T *a, const T *b, const T *c, int64_t rows,
+                                   FastDiv by_sample_stride, FastDiv by_n_samples, FastDiv by_group_rows, int flags)
+{
+    using A = typename Elem<T>::acc;
+    constexpr int D = 1 << LOG2D;
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const uint32_t s = by_n_samples.mod(by_sample_stride.div((uint32_t)r));
+    const uint32_t i = by_group_rows.mod((uint32_t)r);
+    const uint32_t unit = (AXIS == WHVI_AXIS_COL) ? (uint32_t)D : by_group_rows.d;
+    auto factor = [&](const T *vec, bool per_sample, int j) -> A {
+        const size_t base = per_sample ? (size_t)s * unit : 0;
+        return (A)vec[base + (AXIS == WHVI_AXIS_COL ? (uint32_t)j : i)];
+    };
+    A v[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        if constexpr (EYE) {
+            const A cv = (c != nullptr) ? factor(c, flags & WHVI_FUSED_C_PER_SAMPLE, j) : (A)1;
+            v[j] = ((uint32_t)j == i) ? cv : (A)0;
+        } else {
+            v[j] = (A)src[r * D + j];
+            if (c != nullptr) v[j] = factor(c, flags & WHVI_FUSED_C_PER_SAMPLE, j) * v[j];
+        }
+    }
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+        for (int h = 1; h < D; h *= 2)
+#pragma unroll
+            for (int j = 0; j < D; ++j)
+                if ((j & h) == 0) bfly(v[j], v[j | h]);
+        const T *vec = pass == 0 ? b : a;
+        if (vec != nullptr) {
+#pragma unroll
+            for (int j = 0; j < D; ++j)
+                v[j] = factor(vec, pass == 0 ? true : (bool)(flags & WHVI_FUSED_A_PER_SAMPLE), j) * v[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < D; ++j) dst[r * D + j] = (T)v[j];
+}
+
 }  // namespace whvi
 
