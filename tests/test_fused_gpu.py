@@ -233,3 +233,32 @@ def test_tiny_layers_on_gpu(hip_lib):
         (y.sum() + layer.kl).backward()
         assert y.shape == (6, n_out) and torch.isfinite(y).all() and torch.isfinite(x.grad).all()
         assert layer.forward_mc(x.detach(), 3).shape == (3, 6, n_out)
+
+
+@pytest.mark.parametrize("n_in,n_out", [(2, 5), (2, 2), (1, 1), (1, 3), (3, 1), (2, 1), (5, 7), (7, 2), (16, 4),
+                                        (6, 64), (64, 64), (33, 100)])
+def test_layer_values_vs_numpy_oracle_gpu(n_in, n_out, monkeypatch, hip_lib):
+    """Forward values of every WHVILinear flavour on the GPU against the numpy restatement of the reference
+    (oracle/whvi_oracle.py, itself pinned to the reference's recorded bundles), eps replayed; 1e-5 relative."""
+    torch.manual_seed(n_in * 131 + n_out)
+    layer = WHVILinear(n_in, n_out, lambda_=0.3, bias=True)
+    with torch.no_grad():
+        for n_, p_ in layer.named_parameters():
+            if n_.endswith("g_mu") or n_.endswith("bias"):
+                p_.copy_(torch.randn(p_.shape) * 0.4)
+            if n_.endswith("s1") or n_.endswith("s2"):
+                p_.mul_(20.0)
+    params = {k: v.detach().numpy().copy() for k, v in layer.named_parameters()}
+    ref = wo.layer_from_params(n_in, n_out, 0.3, params)
+    x = torch.randn(9, n_in)
+    n_draws = ref.stack if isinstance(ref, wo.Stacked) else 1
+    d_eps = ref.D_in if isinstance(ref, wo.Stacked) else (ref.square.D if isinstance(ref, wo.Column) else ref.D)
+    eps = [np.random.default_rng(7 + i).standard_normal(d_eps).astype(np.float32) for i in range(n_draws)]
+    want = ref.forward(x.numpy(), eps if isinstance(ref, wo.Stacked) else eps[0])
+    layer = layer.to(DEV)
+    monkeypatch.setattr(torch, "randn", ReplayRandn(eps))
+    got = layer(x.to(DEV)).detach().cpu().numpy()
+    monkeypatch.undo()
+    scale = float(np.abs(want).max()) or 1.0
+    assert got.shape == want.shape and np.abs(got - want).max() <= 1e-5 * scale
+    assert abs(float(layer.kl) - float(ref.kl)) <= 1e-5 * abs(float(ref.kl))
