@@ -262,3 +262,29 @@ def test_layer_values_vs_numpy_oracle_gpu(n_in, n_out, monkeypatch, hip_lib):
     scale = float(np.abs(want).max()) or 1.0
     assert got.shape == want.shape and np.abs(got - want).max() <= 1e-5 * scale
     assert abs(float(layer.kl) - float(ref.kl)) <= 1e-5 * abs(float(ref.kl))
+
+
+def test_exploit_diagonal_is_bit_identical(monkeypatch, hip_lib):
+    """The opt-in diagonal shortcut returns the same bits as the faithful FWHT + GEMM path (finite inputs)."""
+    torch.manual_seed(1)
+    layer = WHVILinear(256, 256, bias=True).to(DEV)
+    with torch.no_grad():
+        layer.weight_submodule.g_mu.copy_(torch.randn(256) * 0.3)
+    sq = layer.weight_submodule
+    h = torch.randn(50, 256, device=DEV)
+    eps = [np.random.default_rng(3).standard_normal(256).astype(np.float32)]
+    outs = []
+    for flag in (False, True):
+        sq.exploit_diagonal = flag
+        monkeypatch.setattr(torch, "randn", ReplayRandn(eps))
+        outs.append(layer(h).detach())
+        monkeypatch.undo()
+    assert torch.equal(outs[0], outs[1])
+    eps4 = [np.random.default_rng(10 + i).standard_normal(256).astype(np.float32) for i in range(4)]
+    mc = []
+    for flag in (False, True):
+        sq.exploit_diagonal = flag
+        monkeypatch.setattr(torch, "randn", ReplayRandn(eps4))
+        mc.append(layer.forward_mc(h, 4).detach())
+        monkeypatch.undo()
+    assert torch.allclose(mc[0], mc[1], rtol=1e-6, atol=0)     # batched GEMM may reorder nothing but zeros

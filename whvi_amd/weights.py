@@ -97,6 +97,12 @@ class WHVISquarePow2Matrix(nn.Module):
         self.D = D
         self.lambda_ = lambda_
         self.padding = 0  # interface parity with the stacked matrix
+        # Opt-in shortcut (default off = the reference's dataflow, FWHTs + dense GEMM).  As written in the
+        # reference, w_bar(u) is EXACTLY D * diag(s1 * u * s2) (SURVEY.md finding 1; with butterflies the
+        # off-diagonals are exact zeros), so h @ W.T equals the elementwise h * diag(W) bit for bit for
+        # finite h.  Setting this flag computes that diagonal directly with the same roundings and skips
+        # both the D x D weight construction and the GEMM.
+        self.exploit_diagonal = False
         self.wht_slow = wht_matmul()  # dense-H transform for small host matrices; H built lazily
 
         # creation order = the reference's RNG consumption order (bias, s1, s2, g_mu, g_rho)
@@ -151,10 +157,17 @@ class WHVISquarePow2Matrix(nn.Module):
             return self._w_bar_stack(g_tilde.unsqueeze(0), rows=rows)[0]
         return self.w_bar(g_tilde)
 
+    def _w_bar_diagonal(self, u):
+        """diag(w_bar(u)) with the reference's roundings: s2 * 1 (exact), u * ., the two transforms of a
+        one-hot row (exact: D * .), s1 * ."""
+        return self.s1 * (float(self.D) * (u * self.s2))
+
     def sample_lrt(self, h):
         """``h @ (w_bar(g_mu) + w_bar(g_sigma * eps)).T`` with one eps per call
         (src/weights.py:87-93).  On the GPU both ``w_bar`` matrices come from a single launch."""
         epsilon = torch.randn(self.D, device=self.g_mu.device)
+        if self.exploit_diagonal:
+            return h * (self._w_bar_diagonal(self.g_mu) + self._w_bar_diagonal(self.g_sigma * epsilon))
         if self.g_mu.device.type == "cuda":
             pair = self._w_bar_stack(torch.stack((self.g_mu, self.g_sigma * epsilon)))
             return h @ (pair[0] + pair[1]).T
@@ -173,6 +186,10 @@ class WHVISquarePow2Matrix(nn.Module):
         what ``forward`` computes with the k-th row of one ``randn(n_samples, D)`` draw: one fused
         launch builds every sample's weight matrix, one batched GEMM applies them."""
         eps = torch.randn(n_samples, self.D, device=self.g_mu.device)
+        if self.exploit_diagonal:
+            w = self._w_bar_diagonal(self.g_mu) + self._w_bar_diagonal(self.g_sigma * eps)   # (S, D)
+            out = (x if x.dim() == 3 else x.unsqueeze(0)) * w.unsqueeze(1)
+            return out + self.bias if self.bias is not None else out
         u = torch.cat((self.g_mu.unsqueeze(0), self.g_sigma * eps))             # (1 + S, D)
         if u.device.type == "cuda":
             W = self._w_bar_stack(u)
