@@ -100,12 +100,16 @@ template <> struct Elem<__half> {
     }
     static __device__ __forceinline__ u32x4 pack(const acc (&v)[VEC])
     {
+        // <2 x float> -> <2 x half> fptrunc (round to nearest even) selects gfx950's v_cvt_pk_f16_f32:
+        // one instruction per output dword instead of two converts and an or
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
         u32x4 r;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            uint32_t lo = __half_as_ushort(__float2half_rn(v[2 * i]));
-            uint32_t hi = __half_as_ushort(__float2half_rn(v[2 * i + 1]));
-            r[i] = lo | (hi << 16);
+            const f32x2_t p = {v[2 * i], v[2 * i + 1]};
+            const f16x2_t h = __builtin_convertvector(p, f16x2_t);
+            r[i] = __builtin_bit_cast(uint32_t, h);
         }
         return r;
     }
