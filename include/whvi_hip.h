@@ -75,12 +75,18 @@ int whvi_fwht_i32 (void *dst, const void *src, int64_t rows, int32_t log2d, void
 /* Same transform with an explicit kernel variant, for tuning and for cross-checking the
  * cross-lane code paths against each other on hardware.  variant == 0 is the production launch
  * (what whvi_fwht_<dtype> does); otherwise
- *   bit 0     : 1 = every cross-lane stage through ds_bpermute (__shfl_xor) instead of DPP/permlane
- *   bit 1     : 0 = persistent loop with register prefetch of the next tile, 1 = one tile per wave
- *   bit 2     : 1 = non-temporal loads/stores
- *   bits 4..5 : threads per block, 0 = 256, 1 = 512, 2 = 1024 (no-prefetch variants only)
- *   bits 8..19: cap of the grid in blocks per CU (0 = uncapped)
- * Tuning variants beyond bit 0 exist for f32 and D = 512..4096 only; elsewhere they are ignored.
+ *   bits 0..2 : butterfly network / loop form
+ *                 0  DPP + permlane network, persistent loop with register prefetch of the next tile
+ *                 1,5  every cross-lane stage through ds_bpermute (__shfl_xor), one tile per wave
+ *                 2  DPP + permlane network, one tile per wave, cached accesses
+ *                 3  LDS-staged network (fwht_tile_lds), one tile per wave, cached accesses
+ *                 4  as 0 with non-temporal accesses
+ *                 6  as 2 with non-temporal loads and write-through non-temporal stores (production form)
+ *                 7  as 3 with non-temporal accesses
+ *   bits 4..5 : threads per block, 0 = 256, 1 = 512, 2 = 1024 (576 for the LDS-staged network)
+ *   bits 8..19: cap of the grid in blocks per CU (0 = uncapped: one tile per wave)
+ * Variants other than the ds_bpermute cross-check exist for f32 and D = 512..4096 only; elsewhere only
+ * bit 0 is honoured.  All variants produce identical bits (tests/test_fwht_gpu.py).
  */
 int whvi_fwht_ex(void *dst, const void *src, int64_t rows, int32_t log2d,
                  int32_t dtype, int32_t variant, void *stream);

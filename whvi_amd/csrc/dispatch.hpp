@@ -81,9 +81,7 @@ inline int check_common(const void *dst, const void *src, int64_t rows, int32_t 
 // use 256-thread blocks (more CUs busy) and cached accesses (the consumer is usually next in line).
 constexpr int64_t NT_MIN_BYTES = (int64_t)256 << 20;
 
-// variant word of whvi_fwht_ex (include/whvi_hip.h): bit0 shfl, bit1 no-prefetch, bit2 non-temporal,
-// bits 4..5 block size (0: 256, 1: 512, 2: 1024 threads), bits 8..19 blocks per CU of the grid cap
-// (0 = default: uncapped, one tile per wave), bit 31: use the tuning variant word at all.
+// variant word of whvi_fwht_ex: documented in include/whvi_hip.h (0 = production launch).
 // FULL = the extra tuning variants are compiled (f32, D = 512..4096).
 template <typename T, int LOG2D, int K, bool FULL>
 inline void launch_rows(void *dst, const void *src, int64_t n_chunks, int variant, hipStream_t st)
