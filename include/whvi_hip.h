@@ -142,6 +142,19 @@ int whvi_fused_shs_ex_f64(void *dst, const void *src, const void *a, const void 
                           int64_t sample_stride, int64_t group_rows, int32_t axis,
                           int32_t flags, void *stream);
 
+/* Reparameterisation + KL of J weight matrices in ONE launch, replacing the reference's
+ * chain of small ATen kernels: g_sigma = softplus(g_rho) (src/weights.py:43-50), g_sigma * eps per MC sample
+ * (src/weights.py:82-83,92), and kl_diag_normal(g_mu, g_sigma, 0, lambda) (src/weights.py:52-64,
+ * src/utils.py:49-71, reference argument convention kept).  All buffers f32, contiguous:
+ *   g_mu, g_rho : (J, D)        eps : (J, S, D)  drawn by the caller (injectable, graph-safe)
+ *   u           : (J, 1+S, D)   u[j,0] = g_mu[j],  u[j,1+k] = sigma[j] * eps[j,k]   -> b of whvi_fused_shs_ex
+ *   sigma       : (J, D)        kept for the backward pass
+ *   kl_part     : (J, whvi_reparam_kl_blocks(D))  per-block partial sums; KL[j] = sum over the last axis
+ */
+int whvi_reparam_kl_blocks(int64_t D);
+int whvi_reparam_kl_f32(void *u, void *sigma, void *kl_part, const void *g_mu, const void *g_rho,
+                        const void *eps, int64_t J, int64_t S, int64_t D, float lambda_, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -288,3 +288,27 @@ def test_exploit_diagonal_is_bit_identical(monkeypatch, hip_lib):
         mc.append(layer.forward_mc(h, 4).detach())
         monkeypatch.undo()
     assert torch.allclose(mc[0], mc[1], rtol=1e-6, atol=0)     # batched GEMM may reorder nothing but zeros
+
+
+def test_reparam_kl_kernel_vs_torch_ops(hip_lib):
+    """F3: one launch == softplus / multiply / stack / kl_diag_normal of the reference, forward and backward."""
+    import torch.nn.functional as F
+    from whvi_amd.utils import kl_diag_normal
+    from whvi_amd.weights import ReparamKLFunction
+    torch.manual_seed(2)
+    J, S, D, lam = 3, 5, 700, 0.37            # D not a multiple of 256: partial last block
+    g_mu = (torch.randn(J, D, device=DEV) * 0.5).requires_grad_()
+    g_rho = (torch.rand(J, D, device=DEV) * 25 - 4).requires_grad_()     # crosses softplus' threshold of 20
+    eps = torch.randn(J, S, D, device=DEV)
+    u, kl = ReparamKLFunction.apply(g_mu, g_rho, eps, lam)
+    sig = F.softplus(g_rho)
+    u_ref = torch.cat((g_mu.unsqueeze(1), sig.unsqueeze(1) * eps), dim=1)
+    kl_ref = torch.stack([kl_diag_normal(g_mu[j], sig[j], torch.zeros(D, device=DEV), torch.ones(D, device=DEV) * lam)
+                          for j in range(J)])
+    assert torch.allclose(u, u_ref, rtol=1e-6, atol=1e-7)
+    assert torch.allclose(kl, kl_ref, rtol=1e-5)
+    wu, wk = torch.randn_like(u), torch.randn(J, device=DEV)
+    ga = torch.autograd.grad((u * wu).sum() + (kl * wk).sum(), (g_mu, g_rho))
+    gb = torch.autograd.grad((u_ref * wu).sum() + (kl_ref * wk).sum(), (g_mu, g_rho))
+    for a_, b_ in zip(ga, gb):
+        assert torch.allclose(a_, b_, rtol=1e-4, atol=1e-5 * float(b_.abs().max()))

@@ -296,10 +296,16 @@ def loop_vs_batched(device, monkeypatch):
         net.mc_mode = mode
         net.zero_grad()
         monkeypatch.setattr(torch, "randn", EpsRouter(tables, mode, real))
+        loss = net.loss(x, y, n=90)          # batched mode on the GPU takes the KL from the fused pass
+        monkeypatch.undo()
+        loss.backward()
+        losses = locals().setdefault("losses", {})
+        losses[mode] = float(loss)
+        net.zero_grad()
+        monkeypatch.setattr(torch, "randn", EpsRouter(tables, mode, real))
         pred = net(x)
         monkeypatch.undo()
-        loss = net.likelihood.mnll_batch_estimate(y, pred, 90) + net.kl
-        loss.backward()
+        (net.likelihood.mnll_batch_estimate(y, pred, 90) + net.kl).backward()
         outs[mode] = pred.detach().cpu()
         grads[mode] = torch.cat([p_.grad.reshape(-1) for p_ in net.parameters()]).cpu()
     assert outs["loop"].shape == (9, 1, S)
@@ -307,6 +313,7 @@ def loop_vs_batched(device, monkeypatch):
     assert float((outs["loop"] - outs["batched"]).abs().max()) <= 1e-5 * scale
     gscale = float(grads["loop"].abs().max())
     assert float((grads["loop"] - grads["batched"]).abs().max()) <= 1e-4 * gscale
+    assert abs(losses["loop"] - losses["batched"]) <= 1e-5 * abs(losses["loop"])
 
 
 def test_batched_mc_pass_equals_loop_cpu(monkeypatch):

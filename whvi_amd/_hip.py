@@ -57,6 +57,14 @@ def _declare(lib):
         fn.argtypes = [vp, vp, vp, vp, vp, i64, i32, i64, i64, i64, i32, i32, vp]
 
 
+def _declare_f3(lib):
+    vp, i64 = ctypes.c_void_p, ctypes.c_int64
+    lib.whvi_reparam_kl_blocks.restype = ctypes.c_int
+    lib.whvi_reparam_kl_blocks.argtypes = [i64]
+    lib.whvi_reparam_kl_f32.restype = ctypes.c_int
+    lib.whvi_reparam_kl_f32.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i64, ctypes.c_float, vp]
+
+
 def lib():
     """Load (once) and return the ctypes handle; raise loudly when it is not there."""
     global _lib
@@ -70,6 +78,7 @@ def lib():
                         "`make -C whvi_amd/csrc -j8`. There is no CPU fallback for GPU tensors.")
                 handle = ctypes.CDLL(LIB_PATH)
                 _declare(handle)
+                _declare_f3(handle)
                 if handle.whvi_hip_abi_version() != 1:
                     raise RuntimeError("whvi_amd: libwhvi_hip.so ABI version mismatch")
                 _lib = handle
@@ -187,3 +196,23 @@ def fused_shs(src, a=None, b=None, c=None, *, axis: str = "col", n_samples: int 
                 sample_stride, group_rows, ax, flags, _stream(out))
     _check(rc, "whvi_fused_shs")
     return out
+
+
+def reparam_kl(g_mu: torch.Tensor, g_rho: torch.Tensor, eps: torch.Tensor, lambda_: float):
+    """One launch: (u (J, 1+S, D), sigma (J, D), kl (J,)) from g_mu, g_rho (J, D) and eps (J, S, D);
+    see whvi_reparam_kl_f32 in include/whvi_hip.h."""
+    if g_mu.device.type != "cuda" or g_mu.dtype != torch.float32:
+        raise RuntimeError("reparam_kl: float32 CUDA tensors only")
+    J, D = g_mu.shape
+    S = eps.shape[1]
+    g_mu, g_rho, eps = g_mu.contiguous(), g_rho.contiguous(), eps.contiguous()
+    L = lib()
+    nblk = (D + 255) // 256          # == whvi_reparam_kl_blocks(D)
+    u = torch.empty((J, S + 1, D), dtype=torch.float32, device=g_mu.device)
+    sigma = torch.empty((J, D), dtype=torch.float32, device=g_mu.device)
+    part = torch.empty((J, nblk), dtype=torch.float32, device=g_mu.device)
+    with torch.cuda.device(g_mu.device):
+        rc = L.whvi_reparam_kl_f32(u.data_ptr(), sigma.data_ptr(), part.data_ptr(), g_mu.data_ptr(), g_rho.data_ptr(),
+                                   eps.data_ptr() if S > 0 else None, J, S, D, float(lambda_), _stream(g_mu))
+    _check(rc, "whvi_reparam_kl")
+    return u, sigma, part.sum(dim=1)

@@ -69,3 +69,74 @@ extern "C" __attribute__((visibility("default"))) int whvi_fwht_ex(void *dst, co
     default: g_err[0] = 0; return fail(WHVI_ERR_ARG, "whvi: unknown dtype%s %lld", "", dtype);
     }
 }
+
+namespace whvi {
+
+// ---- F3: reparameterisation + KL of J weight matrices in one launch -----------------------------------
+// Replaces, per layer and forward pass, the reference's chain of small ops (src/weights.py:43-64,82-83,92;
+// src/utils.py:49-71): softplus(g_rho), g_sigma * eps for every MC sample, the stacking of [g_mu; g_sigma*eps]
+// for the fused weight kernel, and the dozen element-wise / reduction launches of kl_diag_normal.
+//   sigma[j,i]  = softplus(g_rho[j,i])                       (torch's threshold-20 form)
+//   u[j,0,i]    = g_mu[j,i];   u[j,1+k,i] = sigma[j,i] * eps[j,k,i]
+//   kl_part[j,b] = sum over the block's i of 0.5*(log(lambda) - log(sigma) - 1 + sigma/lambda + mu*(mu/lambda))
+// i.e. the terms of kl_diag_normal(g_mu, g_sigma, 0, lambda) in the reference's argument convention
+// (sd1 is a standard deviation, sd2 = lambda a variance -- reproduced as is).
+// eps is an INPUT (drawn by torch: injectable for parity tests, graph-safe generator).
+constexpr int REPARAM_SAMPLES_PER_BLOCK = 8;
+
+// grid = (ceil(D/256), J, ceil(S/8)): blockIdx.z owns 8 MC samples so small-D layers with many samples still
+// fill the chip; the z == 0 blocks also write sigma, u[:, 0] and the KL partial sums.
+__global__ void __launch_bounds__(256)
+reparam_kl_kernel(float *u, float *sigma, float *kl_part, const float *g_mu, const float *g_rho, const float *eps,
+                  int S, int D, float lambda_)
+{
+    const int j = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool lead = blockIdx.z == 0;
+    float term = 0.0f;
+    if (i < D) {
+        const float mu = g_mu[(size_t)j * D + i], rho = g_rho[(size_t)j * D + i];
+        const float sg = rho > 20.0f ? rho : log1pf(expf(rho));
+        float *uj = u + (size_t)j * (S + 1) * D + i;
+        const float *ej = eps + (size_t)j * S * D + i;
+        const int k0 = blockIdx.z * REPARAM_SAMPLES_PER_BLOCK;
+        const int k1 = (k0 + REPARAM_SAMPLES_PER_BLOCK < S) ? k0 + REPARAM_SAMPLES_PER_BLOCK : S;
+#pragma unroll 8
+        for (int k = k0; k < k1; ++k) uj[(size_t)(k + 1) * D] = sg * ej[(size_t)k * D];
+        if (lead) {
+            sigma[(size_t)j * D + i] = sg;
+            uj[0] = mu;
+            term = 0.5f * (logf(lambda_) - logf(sg) - 1.0f + sg / lambda_ + mu * (mu / lambda_));
+        }
+    }
+    if (!lead) return;   // block-uniform
+    // block reduction: wave shuffle tree, then one add per wave through LDS (deterministic order)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) term += __shfl_down(term, off, 64);
+    __shared__ float wave_sum[4];
+    if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = term;
+    __syncthreads();
+    if (threadIdx.x == 0) kl_part[(size_t)j * gridDim.x + blockIdx.x] = (wave_sum[0] + wave_sum[1]) + (wave_sum[2] + wave_sum[3]);
+}
+
+}  // namespace whvi
+
+extern "C" __attribute__((visibility("default"))) int whvi_reparam_kl_blocks(int64_t D) { return (int)((D + 255) / 256); }
+
+extern "C" __attribute__((visibility("default")))
+int whvi_reparam_kl_f32(void *u, void *sigma, void *kl_part, const void *g_mu, const void *g_rho, const void *eps,
+                        int64_t J, int64_t S, int64_t D, float lambda_, void *stream)
+{
+    g_err[0] = 0;
+    if (J < 0 || S < 0 || D < 1 || J > 65535 || S > 8 * 65535 || D > (1 << 30))
+        return fail(WHVI_ERR_ARG, "whvi_reparam_kl: bad sizes%s (J=%lld, D=%lld)", "", J, D);
+    if (J == 0) return WHVI_OK;
+    if (!u || !sigma || !kl_part || !g_mu || !g_rho || (S > 0 && !eps))
+        return fail(WHVI_ERR_ARG, "whvi_reparam_kl: null pointer%s", "");
+    if (!(lambda_ > 0.0f)) return fail(WHVI_ERR_ARG, "whvi_reparam_kl: lambda must be positive%s", "");
+    const unsigned gz = (unsigned)((S + REPARAM_SAMPLES_PER_BLOCK - 1) / REPARAM_SAMPLES_PER_BLOCK);
+    hipLaunchKernelGGL(reparam_kl_kernel, dim3((unsigned)((D + 255) / 256), (unsigned)J, gz ? gz : 1u), dim3(256), 0,
+                       (hipStream_t)stream, (float *)u, (float *)sigma, (float *)kl_part, (const float *)g_mu,
+                       (const float *)g_rho, (const float *)eps, (int)S, (int)D, lambda_);
+    return after_launch("reparam_kl");
+}

@@ -43,4 +43,7 @@ class WHVILinear(nn.Module, WHVI):
     def forward_mc(self, x, n_samples):
         """``n_samples`` stochastic passes at once: (batch, n_in) or (n_samples, batch, n_in) ->
         (n_samples, batch, n_out).  Used by ``WHVINetwork`` instead of its per-sample loop."""
-        return self.weight_submodule.forward_mc(x, n_samples)
+        out = self.weight_submodule.forward_mc(x, n_samples)
+        # KL of exactly this pass when the fused reparameterisation kernel produced it (GPU), else None
+        self._mc_kl = getattr(self.weight_submodule, "_mc_kl", None)
+        return out

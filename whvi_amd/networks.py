@@ -75,16 +75,32 @@ class WHVINetwork(nn.Module, WHVI):
         axis ``(S, batch, features)`` from the first WHVI layer on; deterministic modules broadcast
         over it.  Same output layout as the loop: ``(batch, out_dim, n_samples)``."""
         h = x
+        fused_kl, complete = 0.0, True
         for module in self.sequential:
-            h = module.forward_mc(h, n_samples) if hasattr(module, "forward_mc") else module(h)
+            if hasattr(module, "forward_mc"):
+                h = module.forward_mc(h, n_samples)
+                kl = getattr(module, "_mc_kl", None)
+                module._mc_kl = None
+                if kl is None:
+                    complete = False
+                else:
+                    fused_kl = fused_kl + kl
+            else:
+                h = module(h)
+                complete = complete and 'kl' not in dir(module)
+        # sum of the layers' KL terms computed inside this very pass (fused kernel, same parameter values,
+        # same autograd graph); consumed -- once -- by loss()
+        self._pass_kl = fused_kl if complete and torch.is_tensor(fused_kl) else None
         if h.dim() == 2:                      # no stochastic layer at all: identical samples
             h = h.unsqueeze(0).expand(n_samples, *h.shape)
         return h.permute(1, 2, 0)
 
     def loss(self, x, y, n: int, ignore_kl=False) -> torch.Tensor:
         """Negative ELBO estimate = MNLL (+ KL) (src/networks.py:56-69)."""
+        self._pass_kl = None
         self.current_mnll = self.likelihood.mnll_batch_estimate(y, self(x), n)
-        self.current_kl = self.kl
+        pass_kl, self._pass_kl = getattr(self, "_pass_kl", None), None
+        self.current_kl = pass_kl if (pass_kl is not None and not ignore_kl) else self.kl
         return self.current_mnll if ignore_kl else self.current_mnll + self.current_kl
 
     def _epochs(self, data_loader, optimizer, scheduler, epochs, label, ignore_kl, pbar_update_period,

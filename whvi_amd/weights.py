@@ -29,7 +29,7 @@ from whvi_amd.fwht.cuda import FWHTFunction as fwht_cuda
 from whvi_amd.fwht.python import FWHTFunction as fwht_python
 from whvi_amd.fwht.python import WHT_matmul as wht_matmul
 
-__all__ = ["WHVISquarePow2Matrix", "WHVIStackedMatrix", "WHVIColumnMatrix", "WBarFunction"]
+__all__ = ["WHVISquarePow2Matrix", "WHVIStackedMatrix", "WHVIColumnMatrix", "WBarFunction", "ReparamKLFunction"]
 
 
 class WBarFunction(torch.autograd.Function):
@@ -83,6 +83,42 @@ class WBarFunction(torch.autograd.Function):
                 pad = (0, D - R)
                 grad_s1, grad_u, grad_s2 = (F.pad(grad_s1_r, pad), F.pad(grad_u_r, pad), F.pad(grad_s2_r, pad))
         return grad_s1, grad_u, grad_s2, None
+
+
+class ReparamKLFunction(torch.autograd.Function):
+    """``(u, kl) = ReparamKL(g_mu (J, D), g_rho (J, D), eps (J, S, D), lambda)`` in one HIP launch:
+    ``u[:, 0] = g_mu``, ``u[:, 1 + k] = softplus(g_rho) * eps[:, k]`` -- the ``b`` operand of the fused weight
+    kernel -- and ``kl[j] = kl_diag_normal(g_mu[j], softplus(g_rho[j]), 0, lambda)`` with the reference's argument
+    convention (src/weights.py:52-64, src/utils.py:49-71).  Backward in closed form."""
+
+    @staticmethod
+    def forward(ctx, g_mu, g_rho, eps, lambda_):
+        from whvi_amd import _hip
+        u, sigma, kl = _hip.reparam_kl(g_mu, g_rho, eps, lambda_)
+        ctx.save_for_backward(g_mu, g_rho, eps, sigma)
+        ctx.lambda_ = float(lambda_)
+        return u, kl
+
+    @staticmethod
+    def backward(ctx, grad_u, grad_kl):
+        g_mu, g_rho, eps, sigma = ctx.saved_tensors
+        lam = ctx.lambda_
+        gk = grad_kl.unsqueeze(-1)
+        grad_mu = grad_u[:, 0] + gk * (g_mu / lam)
+        grad_sigma = (grad_u[:, 1:] * eps).sum(dim=1) + gk * (0.5 * (1.0 / lam - 1.0 / sigma))
+        grad_rho = grad_sigma * torch.sigmoid(g_rho)
+        grad_eps = grad_u[:, 1:] * sigma.unsqueeze(1) if ctx.needs_input_grad[2] else None
+        return grad_mu, grad_rho, grad_eps, None
+
+
+def _reparam(g_mu, g_rho, eps, lambda_):
+    """(u (J, 1+S, D), kl (J,) or None): one fused launch on the GPU when a loss is being built (autograd
+    on: the KL of this very pass comes for free and its backward is closed-form); the reference's op chain on
+    the host and for pure inference (three tiny launches, less host overhead than the custom Function)."""
+    if g_mu.device.type == "cuda" and g_mu.dtype == torch.float32 and torch.is_grad_enabled():
+        return ReparamKLFunction.apply(g_mu, g_rho, eps, lambda_)
+    sigma = F.softplus(g_rho)
+    return torch.cat((g_mu.unsqueeze(1), sigma.unsqueeze(1) * eps), dim=1), None
 
 
 class WHVISquarePow2Matrix(nn.Module):
@@ -186,11 +222,14 @@ class WHVISquarePow2Matrix(nn.Module):
         what ``forward`` computes with the k-th row of one ``randn(n_samples, D)`` draw: one fused
         launch builds every sample's weight matrix, one batched GEMM applies them."""
         eps = torch.randn(n_samples, self.D, device=self.g_mu.device)
+        self._mc_kl = None
         if self.exploit_diagonal:
             w = self._w_bar_diagonal(self.g_mu) + self._w_bar_diagonal(self.g_sigma * eps)   # (S, D)
             out = (x if x.dim() == 3 else x.unsqueeze(0)) * w.unsqueeze(1)
             return out + self.bias if self.bias is not None else out
-        u = torch.cat((self.g_mu.unsqueeze(0), self.g_sigma * eps))             # (1 + S, D)
+        u, kl = _reparam(self.g_mu.unsqueeze(0), self.g_rho.unsqueeze(0), eps.unsqueeze(0), self.lambda_)
+        u = u[0]                                                                  # (1 + S, D)
+        self._mc_kl = None if kl is None else kl[0]      # KL of this pass, for WHVINetwork.loss
         if u.device.type == "cuda":
             W = self._w_bar_stack(u)
         else:
@@ -273,8 +312,9 @@ class WHVIStackedMatrix(nn.Module):
         s1 = torch.stack([m.s1 for m in self.weight_matrices])
         s2 = torch.stack([m.s2 for m in self.weight_matrices])
         g_mu = torch.stack([m.g_mu for m in self.weight_matrices])
-        g_sigma = F.softplus(torch.stack([m.g_rho for m in self.weight_matrices]))
-        u = torch.cat((g_mu.unsqueeze(1), g_sigma.unsqueeze(1) * eps), dim=1)      # (J, 1 + S, D)
+        g_rho = torch.stack([m.g_rho for m in self.weight_matrices])
+        u, kl = _reparam(g_mu, g_rho, eps, self.lambda_)                            # (J, 1 + S, D)
+        self._mc_kl = None if kl is None else kl.sum()
         if dev.type == "cuda":
             W = WBarFunction.apply(s1, u, s2, None)
         else:
@@ -335,7 +375,9 @@ class WHVIColumnMatrix(nn.Module):
         matrix is ever built."""
         sq = self.weight_submodule
         eps = torch.randn(n_samples, sq.D, device=sq.g_mu.device)
-        g_tilde = sq.g_mu + sq.g_sigma * eps                                        # (S, D_adj)
+        u, kl = _reparam(sq.g_mu.unsqueeze(0), sq.g_rho.unsqueeze(0), eps.unsqueeze(0), sq.lambda_)
+        self._mc_kl = None if kl is None else kl[0]
+        g_tilde = u[0, :1] + u[0, 1:]                                               # (S, D_adj): g_mu + g_sigma * eps
         if g_tilde.device.type == "cuda":
             rows0 = sq._w_bar_stack(g_tilde, rows=1)[:, 0]                           # (S, D_adj)
         else:
