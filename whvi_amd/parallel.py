@@ -105,17 +105,20 @@ def mc_sharded_forward(net, x: torch.Tensor, n_samples: int, base_seed: int = 0)
     begin, end = shard_bounds(n_samples, rank, world)
     counts = [shard_bounds(n_samples, r, world)[1] - shard_bounds(n_samples, r, world)[0] for r in range(world)]
     devices = [x.device] if x.device.type == "cuda" else []
+    n_local = end - begin
     with torch.random.fork_rng(devices=devices):
         torch.manual_seed(sample_seed(base_seed, rank))
-        draws = []
-        for _ in range(end - begin):
-            out = net.sequential(x)
-            draws.append(out.reshape(x.size(0), out.size(-1)))
-    if draws:
-        local = torch.stack(draws, dim=2)
-    else:
-        n_out = net.sequential(x).size(-1)
-        local = torch.zeros(x.size(0), n_out, 0, dtype=x.dtype, device=x.device)
+        if n_local == 0:
+            n_out = net.sequential(x).size(-1)
+            local = torch.zeros(x.size(0), n_out, 0, dtype=x.dtype, device=x.device)
+        elif x.device.type == "cuda" and hasattr(net, "forward_batched"):
+            local = net.forward_batched(x, n_local)          # all local samples in one batched pass
+        else:
+            draws = []
+            for _ in range(n_local):
+                out = net.sequential(x)
+                draws.append(out.reshape(x.size(0), out.size(-1)))
+            local = torch.stack(draws, dim=2)
     return gather_predictions(local, counts)
 
 
