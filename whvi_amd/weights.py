@@ -53,11 +53,16 @@ class WBarFunction(torch.autograd.Function):
         R = D if rows is None else int(rows)
         ctx.save_for_backward(s1, u, s2)
         ctx.rows = R
-        # rows of each (j, k) matrix form one group of R rows; every group carries its own s1/u/s2
-        out = _hip.fused_shs(None, a=s1[:, :R].repeat_interleave(S, dim=0), b=u[:, :, :R],
-                             c=s2[:, :R].repeat_interleave(S, dim=0), axis="row", n_samples=J * S,
-                             sample_stride=R, group_rows=R, rows=J * S * R, d=D, dtype=u.dtype,
-                             device=u.device, a_per_sample=True, c_per_sample=True)
+        # rows of each (j, k) matrix form one group of R rows; with several matrices every group carries its
+        # own s1 / s2 (per-sample outer scales), a single matrix shares them
+        if J == 1:
+            out = _hip.fused_shs(None, a=s1[0, :R], b=u[0, :, :R], c=s2[0, :R], axis="row", n_samples=S,
+                                 sample_stride=R, group_rows=R, rows=S * R, d=D, dtype=u.dtype, device=u.device)
+        else:
+            out = _hip.fused_shs(None, a=s1[:, :R].repeat_interleave(S, dim=0), b=u[:, :, :R],
+                                 c=s2[:, :R].repeat_interleave(S, dim=0), axis="row", n_samples=J * S,
+                                 sample_stride=R, group_rows=R, rows=J * S * R, d=D, dtype=u.dtype,
+                                 device=u.device, a_per_sample=True, c_per_sample=True)
         return out.view(J, S, R, D)
 
     @staticmethod
