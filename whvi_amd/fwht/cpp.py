@@ -1,26 +1,11 @@
-"""Host front-end (mirror of src/fwht/cpp/fwht.py:7-30) on the native OpenMP library."""
-import torch.nn as nn
-from torch.autograd import Function
-
+"""Host front-end on the native OpenMP library; interface of src/fwht/cpp/fwht.py (``FWHTFunction``, ``FWHT``)."""
 import fwht_cpp
+
+from whvi_amd.fwht._frontends import make_fwht_function, make_fwht_module
 
 __all__ = ["FWHTFunction", "FWHT"]
 
-
-class FWHTFunction(Function):
-    """Batched FWHT along dimension 1 of a host tensor (src/fwht/cpp/fwht.py:7-18)."""
-
-    @staticmethod
-    def forward(ctx, x):
-        return fwht_cpp.forward(x)
-
-    @staticmethod
-    def backward(ctx, grad_output):
-        return fwht_cpp.backward(grad_output)
-
-
-class FWHT(nn.Module):
-    """Module wrapper (src/fwht/cpp/fwht.py:21-30)."""
-
-    def forward(self, x):
-        return FWHTFunction.apply(x)
+FWHTFunction = make_fwht_function(
+    fwht_cpp.forward, "FWHTFunction",
+    "Batched FWHT along dimension 1 of a host tensor through ``fwht_cpp.forward`` (libwhvi_cpu.so).")
+FWHT = make_fwht_module(FWHTFunction, "Module form of the host FWHT (src/fwht/cpp/fwht.py:21-30).")

@@ -1,22 +1,11 @@
-"""GPU front-end (mirror of src/fwht/cuda/fwht.py:5-16) on the MI355X HIP kernels."""
-from torch.autograd import Function
-
+"""GPU front-end on the MI355X HIP kernels; interface of src/fwht/cuda/fwht.py (``FWHTFunction.apply(x)``)."""
 import fwht_cuda
+
+from whvi_amd.fwht._frontends import make_fwht_function
 
 __all__ = ["FWHTFunction"]
 
-
-class FWHTFunction(Function):
-    """``FWHTFunction.apply(x)``: batched FWHT of the rows of a 2-D GPU tensor.
-
-    The Walsh-Hadamard matrix is symmetric, so the backward pass is the same transform applied
-    to the incoming gradient (src/fwht/cuda/fwht.py:14-16); going through ``apply`` again keeps
-    it differentiable to any order, as in the reference."""
-
-    @staticmethod
-    def forward(ctx, x):
-        return fwht_cuda.fwht(x)
-
-    @staticmethod
-    def backward(ctx, grad_output):
-        return FWHTFunction.apply(grad_output)
+FWHTFunction = make_fwht_function(
+    fwht_cuda.fwht, "FWHTFunction",
+    "Batched FWHT of the rows of a 2-D GPU tensor through ``fwht_cuda.fwht`` (libwhvi_hip.so); new tensor out, "
+    "input untouched; differentiable to any order.")

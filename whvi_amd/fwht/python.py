@@ -3,9 +3,8 @@ vectorised butterfly.  These are what the reference's model uses for HOST tensor
 (src/weights.py:37-41), so they are kept op-for-op compatible: same operations in the same
 order give the same bits."""
 import torch
-import torch.nn as nn
-from torch.autograd import Function
 
+from whvi_amd.fwht._frontends import make_fwht_function, make_fwht_module
 from whvi_amd.utils import build_H, is_pow_of_2
 
 __all__ = ["WHT_matmul", "FWHTFunction", "FWHT"]
@@ -29,33 +28,24 @@ class WHT_matmul:
         return (self.H @ x.T).T
 
 
-class FWHTFunction(Function):
-    """Vectorised batched FWHT (src/fwht/python/fwht.py:35-63).
+def vectorised_fwht(x: torch.Tensor) -> torch.Tensor:
+    """Batched FWHT of the rows of ``x`` with torch ops only (the algorithm of src/fwht/python/fwht.py:40-55).
 
-    ``transform`` pairs ADJACENT elements first and doubles the trailing axis each round,
-    which is the ascending-stride butterfly network: bit-equal to the C++/HIP transforms."""
-
-    @staticmethod
-    def transform(x: torch.Tensor) -> torch.Tensor:
-        assert x.dim() == 2
-        D = x.size(1)
-        assert is_pow_of_2(D)
-        y = x.unsqueeze(2)
-        rounds = D.bit_length() - 1
-        for _ in range(rounds):
-            even, odd = y[:, ::2], y[:, 1::2]
-            y = torch.cat((even + odd, even - odd), dim=2)
-        return y.squeeze(1)
-
-    @staticmethod
-    def forward(ctx, x):
-        return FWHTFunction.transform(x)
-
-    @staticmethod
-    def backward(ctx, grad_output):
-        return FWHTFunction.transform(grad_output)
+    Every round pairs ADJACENT entries of the shrinking middle axis and appends sums then differences on the
+    growing trailing axis; after log2(D) rounds the trailing axis is the transform.  That is the ascending-stride
+    butterfly network, so the result is bit-equal to the native host and GPU transforms."""
+    assert x.dim() == 2
+    D = x.size(1)
+    assert is_pow_of_2(D)
+    work = x.unsqueeze(2)                                   # (batch, D, 1)
+    for _ in range(D.bit_length() - 1):
+        left, right = work[:, 0::2], work[:, 1::2]
+        work = torch.cat((left + right, left - right), dim=2)
+    return work.squeeze(1)                                  # (batch, 1, D) -> (batch, D)
 
 
-class FWHT(nn.Module):
-    def forward(self, x):
-        return FWHTFunction.apply(x)
+FWHTFunction = make_fwht_function(
+    vectorised_fwht, "FWHTFunction",
+    "Vectorised batched FWHT in torch ops; ``FWHTFunction.transform(x)`` is the raw transform "
+    "(src/fwht/python/fwht.py:35-63).")
+FWHT = make_fwht_module(FWHTFunction, "Module form (src/fwht/python/fwht.py:66-74).")

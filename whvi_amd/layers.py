@@ -1,43 +1,57 @@
-"""WHVI layers (mirror of the reference's src/layers.py)."""
+"""The WHVI layer: interface of the reference's src/layers.py (``WHVILinear(n_in, n_out, lambda_, bias)``,
+``.weight_submodule``, ``.kl``, ``.forward``) plus the batched Monte-Carlo entry point ``forward_mc``."""
 import torch.nn as nn
 
 from whvi_amd.utils import is_pow_of_2
-from whvi_amd.weights import WHVISquarePow2Matrix, WHVIStackedMatrix, WHVIColumnMatrix
+from whvi_amd.weights import WHVIColumnMatrix, WHVISquarePow2Matrix, WHVIStackedMatrix
 
 __all__ = ["WHVI", "WHVILinear"]
 
 
 class WHVI:
-    """Marker base class: anything with a ``kl`` property (src/layers.py:7-16)."""
+    """Mixin marking a module as variational; non-variational members contribute no KL."""
 
     @property
     def kl(self):
         return 0.0
 
 
-class WHVILinear(nn.Module, WHVI):
-    def __init__(self, n_in, n_out, lambda_=1e-5, bias=False):
-        """WHVI feed-forward layer (src/layers.py:19-38).
+def _choose_parameterisation(n_in, n_out, lambda_, bias):
+    """Shape -> weight module, the rule of src/layers.py:31-38:
 
-        Picks the weight parameterisation from the shape: a column matrix when either side is
-        1, a single square matrix when ``n_in == n_out`` is a power of two, a stack otherwise.
-        The chosen module is ``self.weight_submodule`` (state_dict keys depend on that name).
-        """
+    =====================================  ==========================================
+    one input feature                      column matrix (n_out, 1)
+    one output feature                     the same, transposed: row matrix (1, n_in)
+    n_in == n_out, a power of two          one square WHVI matrix
+    anything else                          stack of square blocks of size 2^ceil(log2 n_in)
+    =====================================  ==========================================
+    """
+    if n_in == 1:
+        return WHVIColumnMatrix(n_out, lambda_=lambda_, bias=bias)
+    if n_out == 1:
+        return WHVIColumnMatrix(n_in, lambda_=lambda_, transposed=True, bias=bias)
+    if n_in == n_out and is_pow_of_2(n_in):
+        return WHVISquarePow2Matrix(n_in, lambda_=lambda_, bias=bias)
+    return WHVIStackedMatrix(n_in, n_out, lambda_=lambda_, bias=bias)
+
+
+class WHVILinear(nn.Module, WHVI):
+    """Feed-forward layer whose weight matrix is a Walsh-Hadamard variational factorisation.
+
+    ``lambda_`` is the prior variance; ``bias`` adds a plain (non-variational) bias.  The parameterisation
+    lives in ``self.weight_submodule`` -- that attribute name is part of the checkpoint format."""
+
+    def __init__(self, n_in, n_out, lambda_=1e-5, bias=False):
         super().__init__()
-        if n_in == 1:
-            self.weight_submodule = WHVIColumnMatrix(n_out, lambda_=lambda_, bias=bias)
-        elif n_out == 1:
-            self.weight_submodule = WHVIColumnMatrix(n_in, lambda_=lambda_, transposed=True, bias=bias)
-        elif n_in == n_out and is_pow_of_2(n_in):
-            self.weight_submodule = WHVISquarePow2Matrix(n_in, lambda_=lambda_, bias=bias)
-        else:
-            self.weight_submodule = WHVIStackedMatrix(n_in, n_out, lambda_=lambda_, bias=bias)
+        self.weight_submodule = _choose_parameterisation(n_in, n_out, lambda_, bias)
 
     @property
     def kl(self):
+        """KL from the prior to the variational posterior of this layer's weights."""
         return self.weight_submodule.kl
 
     def forward(self, x):
+        """One stochastic pass (one draw of the weights)."""
         return self.weight_submodule.forward(x)
 
     def forward_mc(self, x, n_samples):
