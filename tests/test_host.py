@@ -332,3 +332,20 @@ def test_batched_mc_pass_reference_bundle(monkeypatch):
     pred = net(torch.from_numpy(g["x"]))
     monkeypatch.undo()
     assert torch.allclose(pred, torch.from_numpy(g["pred"]), rtol=1e-5, atol=1e-6)
+
+
+def test_src_alias_package_matches_reference_import_paths():
+    """``src.*`` (the reference's import paths, README.md:30-33 of the reference) resolve to this package."""
+    import importlib
+    import whvi_amd.layers
+    import whvi_amd.networks
+    assert importlib.import_module("src.layers").WHVILinear is whvi_amd.layers.WHVILinear
+    assert importlib.import_module("src.networks").WHVIRegression is whvi_amd.networks.WHVIRegression
+    for mod, names in (("src.utils", ["matmul_diag_left", "matmul_diag_right", "kl_diag_normal", "build_H", "is_pow_of_2"]),
+                       ("src.weights", ["WHVISquarePow2Matrix", "WHVIStackedMatrix", "WHVIColumnMatrix"]),
+                       ("src.likelihoods", ["GaussianLikelihood", "Likelihood"]),
+                       ("src.fwht.cpp.fwht", ["FWHTFunction", "FWHT"]), ("src.fwht.cuda.fwht", ["FWHTFunction"]),
+                       ("src.fwht.python.fwht", ["FWHTFunction", "WHT_matmul", "FWHT"])):
+        m = importlib.import_module(mod)
+        for n in names:
+            assert hasattr(m, n), (mod, n)
