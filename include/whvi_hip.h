@@ -61,7 +61,9 @@ extern "C" {
 
 int         whvi_hip_abi_version(void);
 const char *whvi_last_error(void);          /* thread-local; "" when the last call succeeded */
-int         whvi_max_log2d(int32_t dtype);  /* largest supported log2(D) for the dtype       */
+int         whvi_max_log2d(int32_t dtype);  /* largest supported log2(D): 24 for f32/f64/i32 (rows beyond
+                                             * 8192 / 4096 elements take extra high-bit passes), 13 for
+                                             * f16/bf16 (single pass only: one rounding)              */
 
 /* Batched row FWHT: dst[r, :] = FWHT(src[r, :]) for r in [0, rows).
  * Replaces fwht_cuda_frontend (fwht_cuda_kernel.cu:156-181) + the X.clone() of

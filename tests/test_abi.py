@@ -40,15 +40,16 @@ def test_argument_checks_without_gpu():
     p16 = (p + 15) & ~15
     assert L.whvi_fwht_f32(None, None, 4, 3, None) == -1 and "null" in _hip.last_error()
     assert L.whvi_fwht_f32(p16, p16, -1, 3, None) == -1
-    assert L.whvi_fwht_f32(p16, p16, 1, 14, None) == -2 and "supported range" in _hip.last_error()
-    assert L.whvi_fwht_f64(p16, p16, 1, 13, None) == -2
+    assert L.whvi_fwht_f32(p16, p16, 1, 25, None) == -2 and "supported range" in _hip.last_error()
+    assert L.whvi_fwht_f64(p16, p16, 1, 25, None) == -2
+    assert L.whvi_fused_shs_f32(p16, p16, None, None, None, 1, 14, 1, 1, 1, 1, None) == -2   # fused: one-wave rows only
     assert L.whvi_fwht_f32(p16 + 4, p16 + 4, 1, 3, None) == -3 and "aligned" in _hip.last_error()
     assert L.whvi_fwht_f32(p16, p16 + 16, 1, 3, None) == -5          # partial overlap
     assert L.whvi_fwht_ex(p16, p16, 1, 3, 99, 0, None) == -1         # unknown dtype
     assert L.whvi_fwht_f32(None, None, 0, 3, None) == 0 and _hip.last_error() == ""   # empty batch
     assert L.whvi_fused_shs_f32(p16, p16, None, None, None, 1, 3, 0, 1, 1, 1, None) == -1  # n_samples < 1
     assert L.whvi_fused_shs_f32(p16, None, None, None, None, 1, 3, 1, 1, 9, 0, None) == -1  # identity needs group_rows <= D
-    assert [L.whvi_max_log2d(i) for i in range(5)] == [13, 12, 13, 13, 13] and L.whvi_max_log2d(7) == -1
+    assert [L.whvi_max_log2d(i) for i in range(5)] == [24, 24, 13, 24, 13] and L.whvi_max_log2d(7) == -1
 
 
 def test_gpu_tensors_never_fall_back(monkeypatch):

@@ -22,7 +22,7 @@ def _cases():
     out = []
     for i in range(N_CASES):
         dt = dtypes[i % len(dtypes)]
-        log2d = int(rng.integers(0, 14 if dt != torch.float64 else 13))
+        log2d = int(rng.integers(0, 17 if dt not in (torch.float16, torch.bfloat16) else 14))   # incl. multi-pass rows
         d = 1 << log2d
         budget = int(rng.choice([1 << 14, 1 << 20, 1 << 25, 1 << 27]))          # elements
         rows = max(1, int(budget // d * rng.uniform(0.5, 1.5)))

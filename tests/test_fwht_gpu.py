@@ -37,7 +37,9 @@ def _oracle(x: torch.Tensor) -> torch.Tensor:
 @pytest.mark.parametrize("variant", [0, 1])
 def test_bit_exact_all_sizes(log2d, dtype, variant, hip_lib):
     if log2d > _hip.max_log2d(dtype):
-        pytest.skip("beyond the single-wave row limit for this dtype")
+        pytest.skip("16-bit storage types are single-pass only")
+    if log2d > (12 if dtype == torch.float64 else 13) and variant != 0:
+        pytest.skip("beyond the single-wave row limit: only the production (multi-pass) launch applies")
     d = 1 << log2d
     for rows in (1, 19, 67):   # odd batches like test/walsh.py:73; 67 rows -> a partial last tile
         x = _rand(rows, d, dtype, seed=1000 * log2d + rows)
@@ -105,7 +107,7 @@ def test_error_behaviour(hip_lib):
     with pytest.raises(RuntimeError, match="n must be a power of 2"):
         fwht_cuda.fwht(torch.randn(2, 6, device=DEV))
     with pytest.raises(RuntimeError, match="outside the supported range"):
-        fwht_cuda.fwht(torch.randn(1, 1 << 15, device=DEV))
+        fwht_cuda.fwht(torch.randn(1, 1 << 25, device=DEV))
     assert fwht_cuda.fwht(torch.empty(0, 8, device=DEV)).shape == (0, 8)
 
 
@@ -187,3 +189,28 @@ def test_side_stream_and_autograd_thread(hip_lib):
     w = torch.randn_like(x)
     (FWHTFunction.apply(xr) * w).sum().backward()
     assert torch.equal(xr.grad, fwht_cuda.fwht(w))       # d/dx <w, xH> = wH (H symmetric)
+
+
+@pytest.mark.parametrize("dtype,log2d", [(torch.float32, 14), (torch.float32, 15), (torch.float32, 17), (torch.float32, 20),
+                                         (torch.float64, 13), (torch.float64, 16), (torch.int32, 16), (torch.int32, 19)])
+def test_rows_longer_than_one_wave(dtype, log2d, hip_lib):
+    """D beyond the register-resident limit (the reference's fwht_batch2 territory, dead code there): row kernel on
+    4096-element pieces + ascending high-bit passes; bit-exact vs the oracle, out of place and in place."""
+    d = 1 << log2d
+    for rows in (1, 3):
+        x = _rand(rows, d, dtype, seed=77 + log2d + rows)
+        want = _oracle(x)
+        xd = x.to(DEV)
+        got = _hip.fwht_rows(xd)
+        assert torch.equal(got.cpu().view(torch.uint8), want.view(torch.uint8)), (dtype, log2d, rows)
+        assert torch.equal(xd.cpu().view(torch.uint8), x.view(torch.uint8)), "input must stay untouched"
+        _hip.fwht_rows(xd, out=xd)
+        assert torch.equal(xd.cpu().view(torch.uint8), want.view(torch.uint8))
+
+
+def test_half_types_reject_multi_pass_lengths(hip_lib):
+    """fp16 / bf16 promise one rounding of the f32 result; a second pass would round the intermediate, so rows
+    beyond the single-wave limit are refused instead of silently losing bits."""
+    for dt in (torch.float16, torch.bfloat16):
+        with pytest.raises(RuntimeError, match="outside the supported range"):
+            _hip.fwht_rows(torch.zeros(1, 1 << 14, dtype=dt, device=DEV))

@@ -13,12 +13,14 @@ int fail(int code, const char *fmt, const char *a = "", long long x = 0, long lo
 int after_launch(const char *what);
 int num_cu();
 
-template <typename T> constexpr int max_log2d()
-{
-    // log2(VEC) + 6 lane bits + log2(Kmax): f32/i32 2+6+5 (K=32) = 13; f16/bf16 3+6+4 (K=16) = 13;
-    // f64 1+6+5 (K=32) = 12.  Beyond that a row no longer fits one wave's registers.
-    return sizeof(T) == 8 ? 12 : 13;
-}
+// Largest row one wavefront holds in registers: log2(VEC) + 6 lane bits + log2(Kmax): f32/i32 2+6+5 (K=32) = 13;
+// f16/bf16 3+6+4 (K=16) = 13; f64 1+6+5 (K=32) = 12.  Longer rows take the row kernel on 2^LOW-element pieces
+// plus high-bit passes (fwht_high_kernel).
+template <typename T> constexpr int max_single_pass_log2d() { return sizeof(T) == 8 ? 12 : 13; }
+template <typename T> constexpr int multi_pass_low_log2d() { return sizeof(T) == 8 ? 11 : 12; }   // 64-VGPR tiles
+// 16-bit storage types stay single-pass: their contract is ONE rounding of the f32 result, and a pass boundary
+// would round the intermediate too.
+template <typename T> constexpr int max_log2d() { return sizeof(T) == 2 ? max_single_pass_log2d<T>() : 24; }
 
 // K = 16-byte chunks per lane: the smallest power of two that holds one row, but never below
 // the streaming size -- as many chunks as keep the tile at 64 data VGPRs (f32/i32/f64: 16 chunks =
@@ -163,10 +165,36 @@ inline int fwht_dispatch(void *dst, const void *src, int64_t rows, int32_t log2d
     constexpr int VEC = Elem<T>::VEC;
     const int64_t n_chunks = elems / VEC;   // whole 16-byte chunks
     const int64_t tail_elems = elems - n_chunks * VEC;
+    if constexpr (sizeof(T) != 2) if (log2d > max_single_pass_log2d<T>()) {
+        // pass 1: index bits [0, LOW) on contiguous 2^LOW-element pieces (src -> dst)
+        constexpr int LOW = multi_pass_low_log2d<T>();
+        launch_rows<T, LOW, pick_k<T, LOW>(), false>(dst, src, n_chunks, 0, st);
+        // passes 2..: bits [LOW, log2d), up to HBMAX at a time, in place on dst
+        constexpr int HBMAX = 4;                               // 2^4 chunks = 64 accumulator VGPRs per thread
+        constexpr int LV = ilog2(VEC);
+        for (int b0 = LOW; b0 < log2d;) {
+            const int hb = (log2d - b0 < HBMAX) ? (log2d - b0) : HBMAX;
+            const int64_t n_groups = n_chunks >> hb;
+            const unsigned grid = (unsigned)((n_groups + 255) / 256);
+            u32x4 *d = (u32x4 *)dst;
+#define WHVI_HIGH(HB) hipLaunchKernelGGL((fwht_high_kernel<T, HB>), dim3(grid), dim3(256), 0, st, d, d, n_groups, b0 - LV)
+            switch (hb) {
+            case 1: WHVI_HIGH(1); break;
+            case 2: WHVI_HIGH(2); break;
+            case 3: WHVI_HIGH(3); break;
+            default:
+                if constexpr (HBMAX >= 4) WHVI_HIGH(4);
+                break;
+            }
+#undef WHVI_HIGH
+            b0 += hb;
+        }
+        return after_launch("fwht (multi-pass)");
+    }
 
 #define WHVI_CASE(L)                                                                                 \
     case L:                                                                                          \
-        if constexpr (L <= max_log2d<T>()) {                                                         \
+        if constexpr (L <= max_single_pass_log2d<T>()) {                                             \
             if (n_chunks > 0)                                                                        \
                 launch_rows<T, L, pick_k<T, L>(), (TUNABLE && L >= 9 && L <= 12)>(dst, src, n_chunks, \
                                                                                   variant, st);      \
@@ -259,7 +287,7 @@ inline int fused_dispatch(void *dst, const void *src, const void *a, const void 
                           int64_t group_rows, int32_t axis, int32_t flags, void *stream)
 {
     constexpr int LV = ilog2(Elem<T>::VEC);
-    int rc = check_common(dst, src, rows, log2d, max_log2d<T>(), sizeof(T), true);
+    int rc = check_common(dst, src, rows, log2d, max_single_pass_log2d<T>(), sizeof(T), true);
     if (rc != WHVI_OK) return rc;
     if (axis != WHVI_AXIS_ROW && axis != WHVI_AXIS_COL)
         return fail(WHVI_ERR_ARG, "whvi: bad axis%s %lld", "", axis);
@@ -297,7 +325,7 @@ inline int fused_dispatch(void *dst, const void *src, const void *a, const void 
     }
 #define WHVI_CASE(L)                                                                                     \
     case L:                                                                                              \
-        if constexpr (L >= LV && L <= max_log2d<T>())                                                    \
+        if constexpr (L >= LV && L <= max_single_pass_log2d<T>())                                        \
             launch_fused<T, L>(dst, src, a, b, c, rows, n_samples, sample_stride, group_rows, axis, flags, st); \
         break;
     switch (log2d) {

@@ -262,6 +262,41 @@ fwht_rows_kernel(u32x4 *dst, const u32x4 *src, int64_t n_chunks, int64_t n_tiles
     }
 }
 
+// ---- rows longer than one wave's registers: high-bit pass ---------------------------------------------
+// For D = 2^n beyond the single-wave limit the transform factors as H_D = H_{2^(n-LOW)} (x) H_{2^LOW}: the
+// row kernel above does index bits [0, LOW) on the 2^LOW-element pieces, then this kernel does HB more bits
+// per pass, ascending, on elements 2^b0 apart (b0 >= LOW: whole 16-byte chunks, so adjacent threads still
+// touch adjacent chunks).  Same adds in the same order as the one-pass network -> same bits.  This is the role
+// of the reference's fwht_batch2_kernel (src/fwht/cuda/fwht_cuda_kernel.cu:35-67, one radix-4 pass per launch
+// for log2 D > 14), with up to 4 stages per pass instead of 2.
+template <typename T, int HB>
+__global__ void __launch_bounds__(256)
+fwht_high_kernel(u32x4 *dst, const u32x4 *src, int64_t n_groups, int log2_stride_chunks)
+{
+    using E = Elem<T>;
+    using A = typename E::acc;
+    constexpr int VEC = E::VEC;
+    constexpr int R = 1 << HB;
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= n_groups) return;
+    const int64_t stride = (int64_t)1 << log2_stride_chunks;
+    const int64_t lo = gid & (stride - 1), hi = gid >> log2_stride_chunks;
+    const int64_t base = (hi << (log2_stride_chunks + HB)) | lo;
+    A v[R][VEC];
+#pragma unroll
+    for (int m = 0; m < R; ++m) E::unpack(src[base + m * stride], v[m]);
+#pragma unroll
+    for (int h = 1; h < R; h *= 2)
+#pragma unroll
+        for (int m = 0; m < R; ++m)
+            if ((m & h) == 0) {
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) bfly(v[m][c], v[m | h][c]);
+            }
+#pragma unroll
+    for (int m = 0; m < R; ++m) dst[base + m * stride] = E::pack(v[m]);
+}
+
 // Rows shorter than one 16-byte chunk whose total size is not a multiple of 16 bytes leave a
 // sub-chunk tail of whole rows; one thread per tail row finishes it.
 template <typename T, int LOG2D>
