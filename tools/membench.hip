@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(B) row_tile(u32x4 *buf, int64_t n_blocks)
 // equal, walk one contiguous eighth of the buffer); OOP: write to a second buffer.
 #define GLD(MODS) asm volatile("global_load_dwordx4 %0, %1, off" MODS : "=v"(c[k]) : "v"(p + k * 64) : "memory")
 #define GST(MODS) asm volatile("global_store_dwordx4 %0, %1, off" MODS :: "v"(q + k * 64), "v"(c[k]) : "memory")
-template <int LD, int ST, int MAP, bool OOP, int B>
+template <int LD, int ST, int MAP, bool OOP, int B, int BAR = 0>
 __global__ void __launch_bounds__(B) policy_tile(u32x4 *buf, u32x4 *out, int64_t n_tiles)
 {
     constexpr int K = 16;
@@ -117,6 +117,14 @@ __global__ void __launch_bounds__(B) policy_tile(u32x4 *buf, u32x4 *out, int64_t
         else GLD(" sc0 sc1");
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (BAR == 1) __syncthreads();      // all 16 waves of the block store their 256 KiB together
+    if constexpr (BAR == 2) {                     // emulate compute skew between waves, then re-align
+        for (int i = 0; i < (wave & 3); ++i) __builtin_amdgcn_s_sleep(100);
+    }
+    if constexpr (BAR == 3) {
+        for (int i = 0; i < (wave & 3); ++i) __builtin_amdgcn_s_sleep(100);
+        __syncthreads();
+    }
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         c[k][0] ^= 1u;
@@ -129,6 +137,22 @@ __global__ void __launch_bounds__(B) policy_tile(u32x4 *buf, u32x4 *out, int64_t
         else if constexpr (ST == 1) GST(" sc0");
         else GST(" sc0 sc1");
     }
+}
+
+// K = 1 (1 KiB per wave) with an artificial delay between the load and the store: does the K = 1 advantage
+// come from writing a line back right after reading it (DRAM row still open)?
+template <int SLEEPS, int NT>
+__global__ void __launch_bounds__(64) lag_tile(u32x4 *buf, int64_t n_tiles)
+{
+    const int64_t t = blockIdx.x;
+    if (t >= n_tiles) return;
+    u32x4 *p = buf + t * 64 + threadIdx.x;
+    u32x4 v = ld<NT>(p);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < SLEEPS; ++i) __builtin_amdgcn_s_sleep(127);   // 127 * 64 cycles ~ 3.4 us each
+    v[0] ^= 1u;
+    st<NT>(p, v);
 }
 
 // BLOCK tiles: block of B threads owns B*K chunks, thread i chunk k*B+i (elementwise-kernel layout)
@@ -160,10 +184,10 @@ static float time_ms(void (*launch)(void *), void *ctx, int iters)
 }
 
 struct Ctx { u32x4 *buf; int64_t chunks; int grid; int lds; u32x4 *out; };
-template <int LD, int ST, int MAP, bool OOP, int B> static void l_policy(void *p)
+template <int LD, int ST, int MAP, bool OOP, int B, int BAR = 0> static void l_policy(void *p)
 {
     Ctx *c = (Ctx *)p; int64_t tiles = c->chunks / (64 * 16);
-    hipLaunchKernelGGL((policy_tile<LD, ST, MAP, OOP, B>), dim3((unsigned)(tiles / (B / 64))), dim3(B), 0, 0,
+    hipLaunchKernelGGL((policy_tile<LD, ST, MAP, OOP, B, BAR>), dim3((unsigned)(tiles / (B / 64))), dim3(B), 0, 0,
                        c->buf, c->out, tiles);
 }
 
@@ -178,6 +202,11 @@ template <int K, int B, int NT, int SYNC> static void l_row(void *p)
 {
     Ctx *c = (Ctx *)p; int64_t blocks = c->chunks / ((int64_t)B * K);
     hipLaunchKernelGGL((row_tile<K, B, NT, SYNC>), dim3((unsigned)blocks), dim3(B), c->lds, 0, c->buf, blocks);
+}
+template <int SLEEPS, int NT> static void l_lag(void *p)
+{
+    Ctx *c = (Ctx *)p; int64_t tiles = c->chunks / 64;
+    hipLaunchKernelGGL((lag_tile<SLEEPS, NT>), dim3((unsigned)tiles), dim3(64), 0, 0, c->buf, tiles);
 }
 template <int K, int B, int NT> static void l_block(void *p)
 {
@@ -197,24 +226,13 @@ int main(int argc, char **argv)
 #define RUN(name, fn, g) do { c.grid = g; float ms = time_ms(fn, &c, 6); printf("%-44s grid %7d : %7.3f ms  %5.2f TB/s\n", name, g, ms, tb / (ms * 1e-3)); fflush(stdout); } while (0)
     c.lds = 0;
     CK(hipMalloc(&c.out, bytes));
-    RUN("policy ld=nt st=nt          (production)", (l_policy<4, 4, 0, false, 1024>), 0);
-    RUN("policy ld=plain st=plain", (l_policy<0, 0, 0, false, 1024>), 0);
-    RUN("policy ld=nt st=plain", (l_policy<4, 0, 0, false, 1024>), 0);
-    RUN("policy ld=plain st=nt", (l_policy<0, 4, 0, false, 1024>), 0);
-    RUN("policy ld=sc0nt st=nt", (l_policy<5, 4, 0, false, 1024>), 0);
-    RUN("policy ld=sc1nt st=nt", (l_policy<6, 4, 0, false, 1024>), 0);
-    RUN("policy ld=sc0sc1nt st=nt", (l_policy<7, 4, 0, false, 1024>), 0);
-    RUN("policy ld=nt st=sc0nt", (l_policy<4, 5, 0, false, 1024>), 0);
-    RUN("policy ld=nt st=sc1nt", (l_policy<4, 6, 0, false, 1024>), 0);
-    RUN("policy ld=nt st=sc0sc1nt", (l_policy<4, 7, 0, false, 1024>), 0);
-    RUN("policy ld=sc1 st=sc1", (l_policy<2, 2, 0, false, 1024>), 0);
-    RUN("policy ld=sc0sc1 st=sc0sc1", (l_policy<3, 3, 0, false, 1024>), 0);
-    RUN("policy ld=nt st=nt XCD-contiguous", (l_policy<4, 4, 1, false, 1024>), 0);
-    RUN("policy ld=plain st=plain XCD-contiguous", (l_policy<0, 0, 1, false, 1024>), 0);
-    RUN("policy ld=nt st=nt out-of-place", (l_policy<4, 4, 0, true, 1024>), 0);
-    RUN("policy ld=plain st=plain out-of-place", (l_policy<0, 0, 0, true, 1024>), 0);
-    RUN("policy ld=nt st=nt out-of-place XCD-contig", (l_policy<4, 4, 1, true, 1024>), 0);
-    RUN("policy ld=nt st=nt B=512", (l_policy<4, 4, 0, false, 512>), 0);
-    RUN("policy ld=nt st=nt B=512 XCD-contiguous", (l_policy<4, 4, 1, false, 512>), 0);
+    for (int rep = 0; rep < 2; ++rep) {
+    RUN("prod-like (nt / sc1nt / XCD / B=1024)", (l_policy<4, 6, 1, false, 1024, 0>), 0);
+    RUN("  + barrier before stores", (l_policy<4, 6, 1, false, 1024, 1>), 0);
+    RUN("  + wave skew (0-3 x 2.7us) before stores", (l_policy<4, 6, 1, false, 1024, 2>), 0);
+    RUN("  + wave skew, then barrier", (l_policy<4, 6, 1, false, 1024, 3>), 0);
+    RUN("B=512 prod-like", (l_policy<4, 6, 1, false, 512, 0>), 0);
+    RUN("B=512 + barrier", (l_policy<4, 6, 1, false, 512, 1>), 0);
+    }
     return 0;
 }

@@ -47,9 +47,9 @@ template <typename T, int LOG2D> constexpr int big_block()
 {
     if (tile_vgprs<T, pick_k<T, LOG2D>()>() > 64) return 256;
     if (std::is_same<T, float>::value) return (LOG2D >= 7 || LOG2D <= 2) ? 1024 : 512;
-    if (std::is_same<T, int32_t>::value) return 1024;
-    if (std::is_same<T, double>::value) return (LOG2D >= 5) ? 1024 : 512;
-    if (std::is_same<T, __hip_bfloat16>::value) return (LOG2D >= 8 || LOG2D <= 4) ? 1024 : 512;
+    if (std::is_same<T, int32_t>::value) return (LOG2D >= 7 || LOG2D <= 2) ? 1024 : 512;
+    if (std::is_same<T, double>::value) return (LOG2D >= 6) ? 1024 : 512;
+    if (std::is_same<T, __hip_bfloat16>::value) return (LOG2D >= 8 || LOG2D <= 3) ? 1024 : 512;
     return 512;   // __half: the pack/unpack temporaries do not fit 128 VGPRs
 }
 

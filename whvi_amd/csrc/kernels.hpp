@@ -242,6 +242,9 @@ fwht_rows_kernel(u32x4 *dst, const u32x4 *src, int64_t n_chunks, int64_t n_tiles
                 for (int k = 0; k < K; ++k) E::unpack(raw[k], r[k]);
             }
             transform(r);
+            // (Tried: a block barrier here so the 16 waves store their 256 KiB together.  A copy microbenchmark
+            // gains 5 % from it, the real kernel LOSES 8 %: the waves leave the butterflies microseconds apart
+            // and the barrier turns that skew into idle time.  profiles/r01/membench_6_store_alignment.log.)
             store_tile(t, r);
         }
     } else {
