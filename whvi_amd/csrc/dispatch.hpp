@@ -218,12 +218,11 @@ inline int fwht_dispatch(void *dst, const void *src, int64_t rows, int32_t log2d
 }
 
 // ---- fused pipeline --------------------------------------------------------------------------
-template <typename T, int LOG2D>
+template <typename T, int LOG2D, int K = pick_k<T, LOG2D>()>
 inline void launch_fused(void *dst, const void *src, const void *a, const void *b, const void *c,
                          int64_t rows, int64_t n_samples, int64_t sample_stride, int64_t group_rows,
                          int axis, int flags, hipStream_t st)
 {
-    constexpr int K = pick_k<T, LOG2D>();
     constexpr int VEC = Elem<T>::VEC;
     constexpr bool SMALL_TILE = tile_vgprs<T, K>() <= 64;
     const int64_t n_chunks = (rows << LOG2D) / VEC;
@@ -246,6 +245,7 @@ inline void launch_fused(void *dst, const void *src, const void *a, const void *
     // vectors in LDS is worth +5 %, non-temporal data accesses +4 %, and the LDS-staged butterfly
     // network ties the DPP one (the kernel is bound by its 4x load-instruction stream, not by VALU):
     //   dpp/256/nt/staged 5.05 TB/s | lds/256 5.00 | dpp/256 4.70 | dpp/512/nt 4.04 | lds/512/nt 4.40
+    //   (one 8 KiB row per wave at D = 2048 -- 106 VGPRs, twice the waves -- ties at 4.87; 1024-thread blocks 4.4)
     // WHVI_FUSED_TUNE=<policy 0|2><block 2|5 (unused: always 256)><nt 0|1><stage 0|1> overrides (read once).
     static const char *tune_env = getenv("WHVI_FUSED_TUNE");
     const int t_pol = tune_env ? tune_env[0] - '0' : 0;
