@@ -107,8 +107,18 @@ inline void launch_rows(void *dst, const void *src, int64_t n_chunks, int varian
         const bool nt = n_chunks * 16 >= NT_MIN_BYTES;
         constexpr int BIG = big_block<T, LOG2D>();
         if constexpr (BIG > 256) {
-            if (big && nt) WHVI_LAUNCH(POLICY_DPP, false, true, BIG);
-            else if (big) WHVI_LAUNCH(POLICY_DPP, false, false, BIG);
+            if (big && nt) {
+                // streams: 256-thread blocks (one wave per SIMD: the four waves run in step) with a block
+                // barrier in front of the stores, so each block writes its 64 KiB back together -- measured
+                // 6.33 vs 6.24 TB/s for 1024-thread blocks without the barrier (with it, 1024-thread blocks
+                // fall to 5.7: their waves share SIMDs and leave the butterflies microseconds apart); fp16 5.5 ->
+                // 6.2, bf16 5.0 -> 6.1, i32 5.8 -> 6.3 TB/s (tools/probe_stream_blocks.py)
+                static const bool exp_big_blocks = getenv("WHVI_STREAM_BIG_BLOCKS") != nullptr;   // A/B switch
+                if (exp_big_blocks || sizeof(T) == 8) WHVI_LAUNCH(POLICY_DPP, false, true, BIG);   // f64: 6.0 vs 5.8
+                else
+                    hipLaunchKernelGGL((fwht_rows_kernel<T, LOG2D, K, POLICY_DPP, false, true, 256, 1>),
+                                       dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, st, d, s, n_chunks, n_tiles);
+            } else if (big) WHVI_LAUNCH(POLICY_DPP, false, false, BIG);
             else WHVI_LAUNCH(POLICY_DPP, false, false, 256);
         } else {
             WHVI_LAUNCH(POLICY_DPP, false, false, 256);
@@ -140,11 +150,30 @@ inline void launch_rows(void *dst, const void *src, int64_t n_chunks, int varian
             }
             break;
         case 4: WHVI_LAUNCH(POLICY_DPP, true, true, 256); break;
-        case 6:
-            if (blk == 0) WHVI_LAUNCH(POLICY_DPP, false, true, 256);
-            else if (blk == 1) WHVI_LAUNCH(POLICY_DPP, false, true, 512);
-            else WHVI_LAUNCH(POLICY_DPP, false, true, 1024);
+        case 6: {
+            const int align = (variant >> 6) & 3;   // bits 6..7: store-alignment experiment (uncapped grids only)
+#define WHVI_LAUNCH_A(BLK, AL)                                                                             \
+    hipLaunchKernelGGL((fwht_rows_kernel<T, LOG2D, K, POLICY_DPP, false, true, BLK, AL>),                  \
+                       dim3((unsigned)((n_tiles + (BLK / 64) - 1) / (BLK / 64))), dim3(BLK), 0, st, d, s, n_chunks, n_tiles)
+            if (align == 0 || bpc > 0) {
+                if (blk == 0) WHVI_LAUNCH(POLICY_DPP, false, true, 256);
+                else if (blk == 1) WHVI_LAUNCH(POLICY_DPP, false, true, 512);
+                else if (blk == 2) WHVI_LAUNCH(POLICY_DPP, false, true, 1024);
+                else WHVI_LAUNCH(POLICY_DPP, false, true, 128);
+            } else if (align == 1) {
+                if (blk == 0) WHVI_LAUNCH_A(256, 1);
+                else if (blk == 1) WHVI_LAUNCH_A(512, 1);
+                else if (blk == 2) WHVI_LAUNCH_A(1024, 1);
+                else WHVI_LAUNCH_A(128, 1);
+            } else {
+                if (blk == 0) WHVI_LAUNCH_A(256, 2);
+                else if (blk == 1) WHVI_LAUNCH_A(512, 2);
+                else if (blk == 2) WHVI_LAUNCH_A(1024, 2);
+                else WHVI_LAUNCH_A(128, 2);
+            }
+#undef WHVI_LAUNCH_A
             break;
+        }
         default: WHVI_LAUNCH(POLICY_SHFL, false, false, 256); break;
         }
     } else {

@@ -170,7 +170,7 @@ __device__ __forceinline__ void tile_store_stream(u32x4 *tile_base, int lane, in
 // dst/src: n_chunks 16-byte chunks; tile t = chunks [t*64*K, (t+1)*64*K).  Only the last tile
 // can be partial; its missing chunks belong to rows that do not exist (rows never straddle
 // tiles), so they are read as zero and never stored.
-template <typename T, int LOG2D, int K, int POLICY, bool PREFETCH, bool NT, int BLOCK = 256>
+template <typename T, int LOG2D, int K, int POLICY, bool PREFETCH, bool NT, int BLOCK = 256, int ALIGN = 0>
 __global__ void __launch_bounds__(BLOCK)
 fwht_rows_kernel(u32x4 *dst, const u32x4 *src, int64_t n_chunks, int64_t n_tiles)
 {
@@ -189,7 +189,13 @@ fwht_rows_kernel(u32x4 *dst, const u32x4 *src, int64_t n_chunks, int64_t n_tiles
     int64_t blk = blockIdx.x;
     if (NT && !PREFETCH && (gridDim.x & 7) == 0) blk = (blk & 7) * (int64_t)(gridDim.x >> 3) + (blk >> 3);
     int64_t t = blk * wpb + wave;
-    if (t >= n_tiles) return;
+    // ALIGN (tuning only, one-tile-per-wave launches): 1 = block barrier before the stores, 2 = additionally a
+    // barrier after the loads have landed -- experiments on keeping a block's 256 KiB write-back together.
+    if (t >= n_tiles) {
+        if constexpr (ALIGN >= 2) __syncthreads();
+        if constexpr (ALIGN >= 1) __syncthreads();
+        return;
+    }
     extern __shared__ __attribute__((aligned(16))) char whvi_smem[];
     auto transform = [&](A (&r)[K][VEC]) {
         if constexpr (POLICY == POLICY_LDS)
@@ -241,7 +247,9 @@ fwht_rows_kernel(u32x4 *dst, const u32x4 *src, int64_t n_chunks, int64_t n_tiles
 #pragma unroll
                 for (int k = 0; k < K; ++k) E::unpack(raw[k], r[k]);
             }
+            if constexpr (ALIGN >= 2) __syncthreads();
             transform(r);
+            if constexpr (ALIGN >= 1) __syncthreads();
             // (Tried: a block barrier here so the 16 waves store their 256 KiB together.  A copy microbenchmark
             // gains 5 % from it, the real kernel LOSES 8 %: the waves leave the butterflies microseconds apart
             // and the barrier turns that skew into idle time.  profiles/r01/membench_6_store_alignment.log.)
@@ -390,7 +398,7 @@ fused_shs_kernel(u32x4 *dst, const u32x4 *src, const T *a, const T *b, const T *
         }
         __syncthreads();
     }
-    if (t >= n_tiles) return;
+    if (t >= n_tiles) return;   // (a store-alignment barrier as in fwht_rows_kernel was tried here: neutral)
 
     auto transform = [&](A (&r)[K][VEC]) {
         if constexpr (POLICY == POLICY_LDS)
