@@ -386,7 +386,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "traffic": recorded_traffic(f"fwht_f32_D{d}_rows{rows}"),
-                     "kernel": "whvi::fwht_rows_kernel<float,12,16,DPP,one-tile-per-wave,nontemporal,1024>",
+                     "kernel": "whvi::fwht_rows_kernel<float,12,16,DPP,one-tile-per-wave,nontemporal,256,store-barrier>",
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms_hip_events": round(ev_ms, 4)},
     }
     if rank == 0 and world == 1 and not CPU_PLUMBING:
