@@ -6,12 +6,13 @@ capture-safe (no allocation, no synchronisation, launches on the stream it is gi
 pass can be recorded once into a hipGraph (``torch.cuda.graph``) and replayed: one launch per forward.
 torch's generator is graph-aware, so every replay draws fresh eps.
 
-Inference only: capturing backward + optimizer steps crashed the process with this torch/ROCm pairing when
-tried (tools/toy_train.py), so training stays eager.
+``GraphedTrainStep`` does the same for a whole training step (loss, backward, optimizer): the backward of the
+fused weight kernel runs from the autograd engine's thread and is captured with the rest
+(tools/graph_train_probe.py walks through the stages).
 """
 import torch
 
-__all__ = ["GraphedPredictor"]
+__all__ = ["GraphedPredictor", "GraphedTrainStep"]
 
 
 class GraphedPredictor:
@@ -42,3 +43,51 @@ class GraphedPredictor:
         self.static_x.copy_(x)
         self.graph.replay()
         return self.static_out
+
+
+class GraphedTrainStep:
+    """One optimisation step of a ``WHVINetwork`` -- ``loss(x, y, n)``, ``backward()``, ``optimizer.step()`` --
+    recorded into a hipGraph and replayed: ``loss = step(x, y)``.
+
+    The optimizer must keep its state on the device (``torch.optim.Adam(..., capturable=True)``); learning-rate
+    schedules that change ``lr`` from the host are not captured.  ``x`` / ``y`` keep the example's shapes; the
+    returned loss is a static tensor overwritten by the next call.  Fresh eps are drawn on every replay.
+
+    Build it BEFORE any eager ``backward()`` of the network in this process: gradient accumulators created by an
+    earlier backward pass on the default stream make the capture abort inside the HIP runtime (torch warns about an
+    "AccumulateGrad node's stream" mismatch first)."""
+
+    def __init__(self, net, optimizer, example_x, example_y, n: int, ignore_kl: bool = False, warmup: int = 3):
+        if example_x.device.type != "cuda":
+            raise RuntimeError("GraphedTrainStep needs GPU tensors")
+        for group in optimizer.param_groups:
+            if "capturable" in group and not group["capturable"]:
+                raise RuntimeError("GraphedTrainStep: create the optimizer with capturable=True")
+        self.net, self.optimizer, self.n, self.ignore_kl = net, optimizer, int(n), bool(ignore_kl)
+        self.static_x, self.static_y = example_x.detach().clone(), example_y.detach().clone()
+        dev = example_x.device
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._eager_step()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        optimizer.zero_grad(set_to_none=True)
+        with torch.cuda.graph(self.graph):
+            self.static_loss = net.loss(self.static_x, self.static_y, self.n, ignore_kl=self.ignore_kl)
+            self.static_loss.backward()
+            optimizer.step()
+
+    def _eager_step(self):
+        self.optimizer.zero_grad(set_to_none=True)
+        self.net.loss(self.static_x, self.static_y, self.n, ignore_kl=self.ignore_kl).backward()
+        self.optimizer.step()
+
+    def __call__(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+        if x.shape != self.static_x.shape or y.shape != self.static_y.shape:
+            raise RuntimeError("GraphedTrainStep: batch shape differs from the captured example")
+        self.static_x.copy_(x)
+        self.static_y.copy_(y)
+        self.graph.replay()
+        return self.static_loss.detach()
