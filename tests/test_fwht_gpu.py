@@ -214,3 +214,33 @@ def test_half_types_reject_multi_pass_lengths(hip_lib):
     for dt in (torch.float16, torch.bfloat16):
         with pytest.raises(RuntimeError, match="outside the supported range"):
             _hip.fwht_rows(torch.zeros(1, 1 << 14, dtype=dt, device=DEV))
+
+
+def test_concurrent_host_threads(hip_lib):
+    """The C ABI keeps no global mutable state besides a thread-local error string: four host threads, each on
+    its own stream, transform their own buffers concurrently."""
+    import threading
+    d, rows = 1024, 513
+    inputs = [_rand(rows, d, torch.int32, 100 + i).float().to(DEV) for i in range(4)]
+    outs, errs = [None] * 4, []
+
+    def work(i):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                y = inputs[i]
+                for _ in range(6):          # three H.H = D.I round trips
+                    y = fwht_cuda.fwht(y)
+            st.synchronize()
+            outs[i] = y
+        except Exception as err:            # surfaced below
+            errs.append(err)
+    torch.cuda.synchronize()
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs, errs
+    for i in range(4):
+        assert torch.equal(outs[i], inputs[i] * float(d) ** 3)

@@ -102,8 +102,33 @@ def _check(rc: int, what: str):
         raise RuntimeError(f"{what} failed (code {rc}): {last_error()}")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream(t: torch.Tensor):
+    """hipStream_t of torch's current stream on t's device (raw-handle fast path: no Stream object)."""
+    if _raw_stream is not None:
+        return ctypes.c_void_p(_raw_stream(t.device.index if t.device.index is not None else torch.cuda.current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+class _OnDevice:
+    """``with _OnDevice(dev):`` == ``with torch.cuda.device(dev):`` but free when dev is already current
+    (the kernels launch on the calling thread's current device; the reference never sets it)."""
+    __slots__ = ("dev", "ctx")
+
+    def __init__(self, dev):
+        self.dev, self.ctx = dev, None
+
+    def __enter__(self):
+        idx = self.dev.index
+        if idx is not None and idx != torch.cuda.current_device():
+            self.ctx = torch.cuda.device(self.dev)
+            self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
 
 
 def _aligned(t: torch.Tensor) -> torch.Tensor:
@@ -136,7 +161,7 @@ def fwht_rows(src: torch.Tensor, out: torch.Tensor = None, variant: int = None) 
         if out.shape != src.shape or out.dtype != src.dtype or out.device != src.device:
             raise RuntimeError("fwht: out must match src in shape, dtype and device")
     L = lib()
-    with torch.cuda.device(src.device):
+    with _OnDevice(src.device):
         if variant is None:
             rc = getattr(L, "whvi_fwht_" + _DTYPE_SUFFIX[src.dtype])(
                 out.data_ptr(), src.data_ptr(), rows, log2d, _stream(src))
@@ -191,7 +216,7 @@ def fused_shs(src, a=None, b=None, c=None, *, axis: str = "col", n_samples: int 
         raise RuntimeError("fused_shs: bad out tensor")
     ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
     fn = getattr(lib(), "whvi_fused_shs_ex_" + _DTYPE_SUFFIX[dtype])
-    with torch.cuda.device(device):
+    with _OnDevice(device):
         rc = fn(out.data_ptr(), ptr(src), ptr(a_), ptr(b_), ptr(c_), rows, log2d, n_samples,
                 sample_stride, group_rows, ax, flags, _stream(out))
     _check(rc, "whvi_fused_shs")
@@ -211,7 +236,7 @@ def reparam_kl(g_mu: torch.Tensor, g_rho: torch.Tensor, eps: torch.Tensor, lambd
     u = torch.empty((J, S + 1, D), dtype=torch.float32, device=g_mu.device)
     sigma = torch.empty((J, D), dtype=torch.float32, device=g_mu.device)
     part = torch.empty((J, nblk), dtype=torch.float32, device=g_mu.device)
-    with torch.cuda.device(g_mu.device):
+    with _OnDevice(g_mu.device):
         rc = L.whvi_reparam_kl_f32(u.data_ptr(), sigma.data_ptr(), part.data_ptr(), g_mu.data_ptr(), g_rho.data_ptr(),
                                    eps.data_ptr() if S > 0 else None, J, S, D, float(lambda_), _stream(g_mu))
     _check(rc, "whvi_reparam_kl")
