@@ -157,6 +157,22 @@ int whvi_reparam_kl_blocks(int64_t D);
 int whvi_reparam_kl_f32(void *u, void *sigma, void *kl_part, const void *g_mu, const void *g_rho,
                         const void *eps, int64_t J, int64_t S, int64_t D, float lambda_, void *stream);
 
+/* Backward of the weight construction W[j,k] = S1_j . fwht(diag(u[j,k]) . fwht(diag(s2_j))) (src/weights.py:73)
+ * in ONE launch: reads the incoming gradient once, writes three scalars per row.  The reference obtains the
+ * same quantities from autograd over its op chain (matmul_diag_left backward, src/utils.py:4-12, and
+ * FWHTFunction.backward = FWHT, src/fwht/cuda/fwht.py:14-16): four more FWHT launches and ~10 elementwise /
+ * reduction launches over (J, S, R, D) tensors.  Buffers, all of the entry point's dtype, contiguous:
+ *   grad_w  : (J, S, R, D)  dL/dW, first R <= D rows of every matrix      s1, s2 : (J, D)      u : (J, S, D)
+ *   grad_u  : (J, S, R)     dL/du[j,k,i]
+ *   part_s1 : (J, S, R)     per-sample contributions; dL/ds1[j,i] = sum over k      (likewise part_s2)
+ * log2d in [2, 13] (f32) / [1, 12] (f64). */
+int whvi_wbar_bwd_f32(void *grad_u, void *part_s1, void *part_s2, const void *grad_w, const void *s1,
+                      const void *u, const void *s2, int64_t J, int64_t S, int64_t R, int32_t log2d,
+                      void *stream);
+int whvi_wbar_bwd_f64(void *grad_u, void *part_s1, void *part_s2, const void *grad_w, const void *s1,
+                      const void *u, const void *s2, int64_t J, int64_t S, int64_t R, int32_t log2d,
+                      void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -3,6 +3,8 @@ and of ``WHVILinear`` on the GPU, against the CPU oracle and the reference's rec
 
 Bar: bit-exact vs ``oracle.pipeline`` (separate roundings for every multiply, ascending butterfly
 order); ``WHVILinear`` forward / KL / backward within 1e-5 relative (BASELINE.json north_star)."""
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -338,3 +340,53 @@ def test_graphed_train_step_learns(hip_lib):
     with torch.no_grad():
         rmse = float(torch.sqrt(((net(x).mean(dim=2) - y) ** 2).mean()))
     assert rmse < 0.5
+
+
+@pytest.mark.parametrize("dtype,J,S,D,R", [
+    (torch.float32, 1, 1, 4, 4), (torch.float32, 1, 3, 8, 8), (torch.float32, 2, 2, 64, 64), (torch.float32, 3, 2, 16, 5),
+    (torch.float32, 1, 2, 256, 256), (torch.float32, 2, 3, 512, 512), (torch.float32, 1, 2, 1024, 1000),
+    (torch.float32, 1, 1, 4096, 4096), (torch.float32, 1, 2, 8192, 24), (torch.float32, 5, 1, 32, 1),
+    (torch.float64, 1, 2, 2, 2), (torch.float64, 2, 2, 4, 3), (torch.float64, 1, 2, 128, 128), (torch.float64, 1, 1, 4096, 9)])
+def test_wbar_backward_kernel_vs_composed_chain(dtype, J, S, D, R, hip_lib):
+    """whvi_wbar_bwd (one launch) against the differentiable op chain (4 FWHT launches + elementwise ops, the
+    path create_graph=True takes) and, in exact arithmetic, the closed form the as-written matrix implies:
+    W = D diag(s1 u s2)  =>  dL/du_i = D s1_i s2_i gW_ii, and likewise for s1, s2 (SURVEY.md finding 1)."""
+    g = torch.Generator().manual_seed(J * 1000 + D + R)
+    s1, s2 = (torch.randn(J, D, generator=g, dtype=dtype).to(DEV).requires_grad_() for _ in range(2))
+    u = torch.randn(J, S, D, generator=g, dtype=dtype).to(DEV).requires_grad_()
+    gw = torch.randn(J, S, R, D, generator=g, dtype=dtype).to(DEV)
+    rows = None if R == D else R
+
+    W = WBarFunction.apply(s1, u, s2, rows)
+    fused = torch.autograd.grad(W, (s1, u, s2), gw)                              # grad mode off in backward -> kernel
+    W = WBarFunction.apply(s1, u, s2, rows)
+    chain = torch.autograd.grad(W, (s1, u, s2), gw, create_graph=True)           # differentiable chain
+    tol = 2e-6 if dtype == torch.float32 else 1e-13
+    for name, a, b in zip(("s1", "u", "s2"), fused, chain):
+        scale = float(b.abs().max()) or 1.0
+        assert a.shape == b.shape
+        assert float((a - b.detach()).abs().max()) <= tol * scale * math.sqrt(D), name
+    # closed form (float64 on the host)
+    d64 = lambda t: t.detach().double().cpu()  # noqa: E731
+    diag = torch.diagonal(d64(gw), dim1=2, dim2=3)                               # (J, S, R)
+    s1r, s2r, ur = d64(s1)[:, None, :R], d64(s2)[:, None, :R], d64(u)[:, :, :R]
+    want = {"u": D * s1r * s2r * diag, "s1": (D * ur * s2r * diag).sum(1), "s2": (D * s1r * ur * diag).sum(1)}
+    for name, a in zip(("s1", "u", "s2"), fused):
+        w = want[name]
+        got = d64(a)[..., :R]
+        assert float(d64(a)[..., R:].abs().max() if R < D else 0.0) == 0.0
+        # the chain's rounding noise is relative to the FWHT output magnitude (~ sqrt(D) |gw|), not to the diagonal
+        noise = (1e-6 if dtype == torch.float32 else 1e-14) * D * float(d64(gw).abs().max()) * 8
+        assert float((got - w).abs().max()) <= noise * float(max(s1r.abs().max(), 1) * max(s2r.abs().max(), 1)
+                                                             * max(ur.abs().max(), 1)), name
+
+
+def test_wbar_backward_kernel_rejects_bad_shapes(hip_lib):
+    gw = torch.zeros(1, 1, 4, 4, device=DEV)
+    with pytest.raises(RuntimeError, match="shapes"):
+        _hip.wbar_bwd(gw, torch.zeros(1, 8, device=DEV), torch.zeros(1, 1, 4, device=DEV), torch.zeros(1, 4, device=DEV))
+    with pytest.raises(RuntimeError, match="dtypes"):
+        _hip.wbar_bwd(gw, torch.zeros(1, 4, device=DEV).double(), torch.zeros(1, 1, 4, device=DEV),
+                      torch.zeros(1, 4, device=DEV))
+    assert not _hip.wbar_bwd_supported(torch.float32, 2) and not _hip.wbar_bwd_supported(torch.float64, 8192)
+    assert _hip.wbar_bwd_supported(torch.float32, 8192) and _hip.wbar_bwd_supported(torch.float64, 2)

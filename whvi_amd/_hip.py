@@ -63,6 +63,10 @@ def _declare_f3(lib):
     lib.whvi_reparam_kl_blocks.argtypes = [i64]
     lib.whvi_reparam_kl_f32.restype = ctypes.c_int
     lib.whvi_reparam_kl_f32.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i64, ctypes.c_float, vp]
+    for sfx in ("f32", "f64"):
+        fn = getattr(lib, "whvi_wbar_bwd_" + sfx)
+        fn.restype = ctypes.c_int
+        fn.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, ctypes.c_int32, vp]
 
 
 def lib():
@@ -241,3 +245,30 @@ def reparam_kl(g_mu: torch.Tensor, g_rho: torch.Tensor, eps: torch.Tensor, lambd
                                    eps.data_ptr() if S > 0 else None, J, S, D, float(lambda_), _stream(g_mu))
     _check(rc, "whvi_reparam_kl")
     return u, sigma, part.sum(dim=1)
+
+
+def wbar_bwd_supported(dtype: torch.dtype, d: int) -> bool:
+    """Shapes the one-launch backward covers (rows of one 16-byte chunk up to one wavefront tile)."""
+    if dtype == torch.float32:
+        return 4 <= d <= 8192
+    return dtype == torch.float64 and 2 <= d <= 4096
+
+
+def wbar_bwd(grad_w: torch.Tensor, s1: torch.Tensor, u: torch.Tensor, s2: torch.Tensor):
+    """One launch: (grad_u, part_s1, part_s2), each (J, S, R), from grad_w (J, S, R, D), s1 / s2 (J, D) and
+    u (J, S, D); see whvi_wbar_bwd_f32 in include/whvi_hip.h."""
+    if grad_w.device.type != "cuda" or grad_w.dtype not in (torch.float32, torch.float64):
+        raise RuntimeError("wbar_bwd: float32 / float64 CUDA tensors only")
+    J, S, R, D = grad_w.shape
+    if tuple(u.shape) != (J, S, D) or tuple(s1.shape) != (J, D) or tuple(s2.shape) != (J, D):
+        raise RuntimeError("wbar_bwd: operand shapes do not match grad_w")
+    if not (u.dtype == s1.dtype == s2.dtype == grad_w.dtype):
+        raise RuntimeError("wbar_bwd: operand dtypes do not match grad_w")
+    grad_w, s1, u, s2 = grad_w.contiguous(), s1.contiguous(), u.contiguous(), s2.contiguous()
+    out = torch.empty((3, J, S, R), dtype=grad_w.dtype, device=grad_w.device)
+    fn = getattr(lib(), "whvi_wbar_bwd_" + _DTYPE_SUFFIX[grad_w.dtype])
+    with _OnDevice(grad_w.device):
+        rc = fn(out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), grad_w.data_ptr(), s1.data_ptr(),
+                u.data_ptr(), s2.data_ptr(), J, S, R, D.bit_length() - 1, _stream(grad_w))
+    _check(rc, "whvi_wbar_bwd")
+    return out[0], out[1], out[2]

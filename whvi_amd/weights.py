@@ -44,7 +44,8 @@ class WBarFunction(torch.autograd.Function):
     Forward: ``whvi_fused_shs_ex`` with the identity input synthesised in-kernel (no HBM read),
     row-axis scales c = s2, b = u, a = s1 -- multiply / butterfly order and roundings exactly those
     of src/weights.py:73.  Backward: the adjoint chain (H is symmetric, so every FWHT's adjoint is
-    the same FWHT, src/fwht/cuda/fwht.py:14-16) written with differentiable ops."""
+    the same FWHT, src/fwht/cuda/fwht.py:14-16): one fused launch (``whvi_wbar_bwd``) for first-order
+    gradients, the chain written with differentiable ops when a graph of the backward is requested."""
 
     @staticmethod
     def forward(ctx, s1, u, s2, rows):
@@ -70,6 +71,16 @@ class WBarFunction(torch.autograd.Function):
         s1, u, s2 = ctx.saved_tensors
         J, S, D = u.shape
         R = ctx.rows
+        from whvi_amd import _hip
+        if not torch.is_grad_enabled() and _hip.wbar_bwd_supported(u.dtype, D):
+            # first-order backward (the training loop): one launch, grad_W read once (whvi_wbar_bwd)
+            grad_u_r, part_s1, part_s2 = _hip.wbar_bwd(grad_W, s1, u, s2)
+            grad_s1_r, grad_s2_r = part_s1.sum(dim=1), part_s2.sum(dim=1)
+            if R == D:
+                return grad_s1_r, grad_u_r, grad_s2_r, None
+            pad = (0, D - R)
+            return F.pad(grad_s1_r, pad), F.pad(grad_u_r, pad), F.pad(grad_s2_r, pad), None
+        # create_graph=True (or a shape outside the fused kernel): the same chain as differentiable ops
         fw = fwht_cuda.apply
         with torch.enable_grad():
             s1r, s2r, ur = s1[:, :R], s2[:, :R], u[:, :, :R]
