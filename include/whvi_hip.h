@@ -163,8 +163,8 @@ int whvi_reparam_kl_f32(void *u, void *sigma, void *kl_part, const void *g_mu, c
  * FWHTFunction.backward = FWHT, src/fwht/cuda/fwht.py:14-16): four more FWHT launches and ~10 elementwise /
  * reduction launches over (J, S, R, D) tensors.  Buffers, all of the entry point's dtype, contiguous:
  *   grad_w  : (J, S, R, D)  dL/dW, first R <= D rows of every matrix      s1, s2 : (J, D)      u : (J, S, D)
- *   grad_u  : (J, S, R)     dL/du[j,k,i]
- *   part_s1 : (J, S, R)     per-sample contributions; dL/ds1[j,i] = sum over k      (likewise part_s2)
+ *   grad_u  : (J, S, D)     dL/du[j,k,i] for i < R; entries i >= R are NOT written (zero-fill them when R < D)
+ *   part_s1 : (J, S, D)     per-sample contributions, same convention; dL/ds1[j,i] = sum over k (likewise part_s2)
  * log2d in [2, 13] (f32) / [1, 12] (f64). */
 int whvi_wbar_bwd_f32(void *grad_u, void *part_s1, void *part_s2, const void *grad_w, const void *s1,
                       const void *u, const void *s2, int64_t J, int64_t S, int64_t R, int32_t log2d,
@@ -172,6 +172,29 @@ int whvi_wbar_bwd_f32(void *grad_u, void *part_s1, void *part_s2, const void *gr
 int whvi_wbar_bwd_f64(void *grad_u, void *part_s1, void *part_s2, const void *grad_w, const void *s1,
                       const void *u, const void *s2, int64_t J, int64_t S, int64_t R, int32_t log2d,
                       void *stream);
+
+/* Backward of whvi_reparam_kl_f32 in one launch (closed form): grad_u (J, 1+S, D) and grad_kl (J) are the incoming
+ * gradients (either may be NULL = zero), sigma the forward's saved output; writes grad_mu, grad_rho (J, D).
+ * Replaces autograd over softplus / mul / kl_diag_normal (src/weights.py:43-64,82-83; src/utils.py:49-71). */
+int whvi_reparam_kl_bwd_f32(void *grad_mu, void *grad_rho, const void *grad_u, const void *grad_kl,
+                            const void *g_mu, const void *g_rho, const void *eps, const void *sigma,
+                            int64_t J, int64_t S, int64_t D, float lambda_, void *stream);
+
+/* Gaussian mean negative log likelihood of MC predictions, replacing the per-output Python loop and
+ * the elementwise chain of GaussianLikelihood.mnll_batch_estimate (src/likelihoods.py:18-29) by one reduction:
+ *     part[b] = { scale * sum_b log N(y | y_hat, sigma^2),  sum_b z^2 },   z = (y - y_hat) / sigma
+ * over three index dimensions size[0..2] (HOST arrays) with element strides yhat_stride / y_stride (y broadcasts
+ * with stride 0 along the MC axis; order the dimensions by decreasing y_hat stride for coalesced reads);
+ * mnll = sum_b part[b][0] with scale = -n / (m * n_mc); b < whvi_gauss_mnll_blocks(size[0]*size[1]*size[2]).
+ * sigma is a DEVICE scalar (the learnable likelihood.sigma).  The backward writes
+ *     grad_yhat = g * scale * (y - y_hat) / sigma^2   (same strides as y_hat),
+ *     grad_sigma = g * scale * (sum z^2 - count) / sigma        with g = *grad_out (device scalar). */
+int whvi_gauss_mnll_blocks(int64_t total);
+int whvi_gauss_mnll_f32(void *part, const void *y, const void *y_hat, const void *sigma, const int64_t *size,
+                        const int64_t *yhat_stride, const int64_t *y_stride, float scale, void *stream);
+int whvi_gauss_mnll_bwd_f32(void *grad_yhat, void *grad_sigma, const void *grad_out, const void *part,
+                            const void *y, const void *y_hat, const void *sigma, const int64_t *size,
+                            const int64_t *yhat_stride, const int64_t *y_stride, float scale, void *stream);
 
 #ifdef __cplusplus
 }

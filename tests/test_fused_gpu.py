@@ -388,5 +388,74 @@ def test_wbar_backward_kernel_rejects_bad_shapes(hip_lib):
     with pytest.raises(RuntimeError, match="dtypes"):
         _hip.wbar_bwd(gw, torch.zeros(1, 4, device=DEV).double(), torch.zeros(1, 1, 4, device=DEV),
                       torch.zeros(1, 4, device=DEV))
+    out = _hip.wbar_bwd(torch.ones(1, 2, 3, 8, device=DEV), torch.ones(1, 8, device=DEV), torch.ones(1, 2, 8, device=DEV),
+                        torch.ones(1, 8, device=DEV))
+    assert out.shape == (3, 1, 2, 8) and float(out[..., 3:].abs().max()) == 0.0     # rows i >= R: zero gradient
     assert not _hip.wbar_bwd_supported(torch.float32, 2) and not _hip.wbar_bwd_supported(torch.float64, 8192)
     assert _hip.wbar_bwd_supported(torch.float32, 8192) and _hip.wbar_bwd_supported(torch.float64, 2)
+
+
+def test_reparam_kl_backward_kernel_vs_torch_ops(hip_lib):
+    """whvi_reparam_kl_bwd (one launch) against autograd over the reference's op chain (softplus, mul, kl_diag_normal)."""
+    from whvi_amd.weights import ReparamKLFunction
+    from whvi_amd.utils import kl_diag_normal
+    import torch.nn.functional as F
+    for J, S, D, lam in ((1, 1, 128, 1e-5), (3, 5, 64, 0.3), (2, 0, 16, 1.0), (1, 7, 1000, 2.0)):
+        g = torch.Generator().manual_seed(D + S)
+        mu = torch.randn(J, D, generator=g).to(DEV).requires_grad_()
+        rho = (torch.rand(J, D, generator=g) * 4 - 3)
+        rho[0, 0] = 25.0                                          # above softplus' threshold
+        rho = rho.to(DEV).requires_grad_()
+        eps = torch.randn(J, S, D, generator=g).to(DEV)
+        gu = torch.randn(J, S + 1, D, generator=g).to(DEV)
+        gk = torch.randn(J, generator=g).to(DEV)
+        u, kl = ReparamKLFunction.apply(mu, rho, eps, lam)
+        got = torch.autograd.grad((u, kl), (mu, rho), (gu, gk))
+        sigma = F.softplus(rho)
+        u2 = torch.cat((mu.unsqueeze(1), sigma.unsqueeze(1) * eps), dim=1)
+        kl2 = torch.stack([kl_diag_normal(mu[j], sigma[j], torch.zeros(D, device=DEV), torch.ones(D, device=DEV) * lam)
+                           for j in range(J)])
+        want = torch.autograd.grad((u2, kl2), (mu, rho), (gu, gk), retain_graph=True)
+        for a, b in zip(got, want):
+            assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
+        # KL-only gradient (the incoming gradient of u is None)
+        u, kl = ReparamKLFunction.apply(mu, rho, eps, lam)
+        only_kl = torch.autograd.grad(kl.sum(), (mu, rho))
+        want_kl = torch.autograd.grad(kl2.sum(), (mu, rho))
+        for a, b in zip(only_kl, want_kl):
+            assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
+
+
+@pytest.mark.parametrize("m,n_out,n_mc,layout", [(100, 1, 1, "perm"), (37, 3, 5, "perm"), (64, 2, 8, "contig"),
+                                                 (1, 1, 1, "contig"), (5000, 1, 64, "perm"), (9, 4, 3, "expand")])
+def test_gauss_mnll_kernel_vs_reference_formula(m, n_out, n_mc, layout, hip_lib):
+    """whvi_gauss_mnll (one reduction, strided y_hat) against the reference's estimator (src/likelihoods.py:18-29,
+    per-output loop restated in float64) and its autograd gradients."""
+    from whvi_amd.likelihoods import GaussianLikelihood
+    g = torch.Generator().manual_seed(m + n_mc)
+    y = torch.randn(m, n_out, generator=g).to(DEV)
+    if layout == "perm":                         # what forward_batched returns: (S, batch, out) permuted
+        base = torch.randn(n_mc, m, n_out, generator=g).to(DEV).requires_grad_()
+    elif layout == "expand":                     # a network without stochastic layers
+        base = torch.randn(m, n_out, generator=g).to(DEV).requires_grad_()
+    else:
+        base = torch.randn(m, n_out, n_mc, generator=g).to(DEV).requires_grad_()
+    view = {"perm": lambda t: t.permute(1, 2, 0), "expand": lambda t: t.unsqueeze(2).expand(m, n_out, n_mc),
+            "contig": lambda t: t}[layout]
+    lik = GaussianLikelihood(0.7).to(DEV)
+    n = 4321
+    got = lik.mnll_batch_estimate(y, view(base), n)
+    g_base, g_sigma = torch.autograd.grad(got, (base, lik.sigma))
+    # float64 restatement of the reference loop
+    b64 = base.detach().double().requires_grad_()
+    yh64 = view(b64)
+    s64 = lik.sigma.detach().double().requires_grad_()
+    total = 0.0
+    for o in range(n_out):
+        dist = torch.distributions.Normal(yh64[:, o, :], s64)
+        total = total + dist.log_prob(y.double()[:, o].reshape(m, 1)).sum()
+    want = -n / (m * n_mc) * total
+    w_base, w_sigma = torch.autograd.grad(want, (b64, s64))
+    assert abs(float(got) - float(want)) <= 2e-5 * abs(float(want))
+    assert float((g_base.double() - w_base).abs().max()) <= 2e-5 * float(w_base.abs().max())
+    assert abs(float(g_sigma) - float(w_sigma)) <= 5e-5 * abs(float(w_sigma))

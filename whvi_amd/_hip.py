@@ -63,6 +63,15 @@ def _declare_f3(lib):
     lib.whvi_reparam_kl_blocks.argtypes = [i64]
     lib.whvi_reparam_kl_f32.restype = ctypes.c_int
     lib.whvi_reparam_kl_f32.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i64, ctypes.c_float, vp]
+    lib.whvi_reparam_kl_bwd_f32.restype = ctypes.c_int
+    lib.whvi_reparam_kl_bwd_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, ctypes.c_float, vp]
+    p64 = ctypes.POINTER(ctypes.c_int64)
+    lib.whvi_gauss_mnll_blocks.restype = ctypes.c_int
+    lib.whvi_gauss_mnll_blocks.argtypes = [i64]
+    lib.whvi_gauss_mnll_f32.restype = ctypes.c_int
+    lib.whvi_gauss_mnll_f32.argtypes = [vp, vp, vp, vp, p64, p64, p64, ctypes.c_float, vp]
+    lib.whvi_gauss_mnll_bwd_f32.restype = ctypes.c_int
+    lib.whvi_gauss_mnll_bwd_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, p64, p64, p64, ctypes.c_float, vp]
     for sfx in ("f32", "f64"):
         fn = getattr(lib, "whvi_wbar_bwd_" + sfx)
         fn.restype = ctypes.c_int
@@ -244,7 +253,7 @@ def reparam_kl(g_mu: torch.Tensor, g_rho: torch.Tensor, eps: torch.Tensor, lambd
         rc = L.whvi_reparam_kl_f32(u.data_ptr(), sigma.data_ptr(), part.data_ptr(), g_mu.data_ptr(), g_rho.data_ptr(),
                                    eps.data_ptr() if S > 0 else None, J, S, D, float(lambda_), _stream(g_mu))
     _check(rc, "whvi_reparam_kl")
-    return u, sigma, part.sum(dim=1)
+    return u, sigma, (part.sum(dim=1) if nblk > 1 else part[:, 0])
 
 
 def wbar_bwd_supported(dtype: torch.dtype, d: int) -> bool:
@@ -255,8 +264,8 @@ def wbar_bwd_supported(dtype: torch.dtype, d: int) -> bool:
 
 
 def wbar_bwd(grad_w: torch.Tensor, s1: torch.Tensor, u: torch.Tensor, s2: torch.Tensor):
-    """One launch: (grad_u, part_s1, part_s2), each (J, S, R), from grad_w (J, S, R, D), s1 / s2 (J, D) and
-    u (J, S, D); see whvi_wbar_bwd_f32 in include/whvi_hip.h."""
+    """One launch: a (3, J, S, D) tensor [grad_u, part_s1, part_s2] from grad_w (J, S, R, D), s1 / s2 (J, D) and
+    u (J, S, D); entries i >= R are zero.  See whvi_wbar_bwd_f32 in include/whvi_hip.h."""
     if grad_w.device.type != "cuda" or grad_w.dtype not in (torch.float32, torch.float64):
         raise RuntimeError("wbar_bwd: float32 / float64 CUDA tensors only")
     J, S, R, D = grad_w.shape
@@ -265,10 +274,62 @@ def wbar_bwd(grad_w: torch.Tensor, s1: torch.Tensor, u: torch.Tensor, s2: torch.
     if not (u.dtype == s1.dtype == s2.dtype == grad_w.dtype):
         raise RuntimeError("wbar_bwd: operand dtypes do not match grad_w")
     grad_w, s1, u, s2 = grad_w.contiguous(), s1.contiguous(), u.contiguous(), s2.contiguous()
-    out = torch.empty((3, J, S, R), dtype=grad_w.dtype, device=grad_w.device)
+    alloc = torch.empty if R == D else torch.zeros
+    out = alloc((3, J, S, D), dtype=grad_w.dtype, device=grad_w.device)
     fn = getattr(lib(), "whvi_wbar_bwd_" + _DTYPE_SUFFIX[grad_w.dtype])
     with _OnDevice(grad_w.device):
         rc = fn(out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), grad_w.data_ptr(), s1.data_ptr(),
                 u.data_ptr(), s2.data_ptr(), J, S, R, D.bit_length() - 1, _stream(grad_w))
     _check(rc, "whvi_wbar_bwd")
-    return out[0], out[1], out[2]
+    return out
+
+
+def reparam_kl_bwd(grad_u, grad_kl, g_mu, g_rho, eps, sigma, lambda_: float):
+    """One launch: (grad_mu, grad_rho), each (J, D); see whvi_reparam_kl_bwd_f32 in include/whvi_hip.h.
+    ``grad_u`` (J, 1+S, D) and ``grad_kl`` (J,) may be None (= zero)."""
+    J, D = g_mu.shape
+    S = eps.shape[1]
+    grad_u = None if grad_u is None else grad_u.contiguous()
+    grad_kl = None if grad_kl is None else grad_kl.contiguous()
+    out = torch.empty((2, J, D), dtype=torch.float32, device=g_mu.device)
+    ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+    with _OnDevice(g_mu.device):
+        rc = lib().whvi_reparam_kl_bwd_f32(out[0].data_ptr(), out[1].data_ptr(), ptr(grad_u), ptr(grad_kl),
+                                           g_mu.data_ptr(), g_rho.data_ptr(), eps.data_ptr() if S > 0 else None,
+                                           sigma.data_ptr(), J, S, D, float(lambda_), _stream(g_mu))
+    _check(rc, "whvi_reparam_kl_bwd")
+    return out[0], out[1]
+
+
+def _mnll_dims(y: torch.Tensor, y_hat: torch.Tensor):
+    """Three (size, y_hat stride, y stride) triples, dimensions ordered by decreasing y_hat stride (memory order)."""
+    order = sorted(range(3), key=lambda k: -y_hat.stride(k))
+    arr = ctypes.c_int64 * 3
+    return (arr(*[y_hat.size(k) for k in order]), arr(*[y_hat.stride(k) for k in order]),
+            arr(*[y.stride(k) for k in order]))
+
+
+def gauss_mnll(y: torch.Tensor, y_hat: torch.Tensor, sigma: torch.Tensor, scale: float):
+    """Per-block partial sums (blocks, 2) of whvi_gauss_mnll_f32: ``y_hat`` (m, n_out, n_mc) with any strides,
+    ``y`` an expanded view of the same shape, ``sigma`` a device scalar."""
+    L = lib()
+    part = torch.empty((L.whvi_gauss_mnll_blocks(y_hat.numel()), 2), dtype=torch.float32, device=y_hat.device)
+    size, hs, ys = _mnll_dims(y, y_hat)
+    with _OnDevice(y_hat.device):
+        rc = L.whvi_gauss_mnll_f32(part.data_ptr(), y.data_ptr(), y_hat.data_ptr(), sigma.data_ptr(), size, hs, ys,
+                                   float(scale), _stream(y_hat))
+    _check(rc, "whvi_gauss_mnll")
+    return part
+
+
+def gauss_mnll_bwd(grad_out, part, y, y_hat, sigma, scale: float):
+    """(grad_yhat with y_hat's strides, grad_sigma scalar) of whvi_gauss_mnll_bwd_f32."""
+    grad_yhat = torch.empty_strided(y_hat.size(), y_hat.stride(), dtype=torch.float32, device=y_hat.device)
+    grad_sigma = torch.empty((), dtype=torch.float32, device=y_hat.device)
+    size, hs, ys = _mnll_dims(y, y_hat)
+    with _OnDevice(y_hat.device):
+        rc = lib().whvi_gauss_mnll_bwd_f32(grad_yhat.data_ptr(), grad_sigma.data_ptr(), grad_out.data_ptr(),
+                                           part.data_ptr(), y.data_ptr(), y_hat.data_ptr(), sigma.data_ptr(), size, hs,
+                                           ys, float(scale), _stream(y_hat))
+    _check(rc, "whvi_gauss_mnll_bwd")
+    return grad_yhat, grad_sigma

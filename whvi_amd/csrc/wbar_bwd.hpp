@@ -21,7 +21,7 @@ namespace whvi {
 template <typename A> __device__ __forceinline__ A flip_if(A v, bool neg) { return neg ? -v : v; }
 
 // Tile ownership and index helpers as in fused_shs_kernel.  Rows are (J, S, R) x D, s1 / s2 are (J, D),
-// u is (J, S, D) (only the first R entries of each are used); outputs are (J, S, R).
+// u is (J, S, D) (only the first R entries of each are used); outputs are (J, S, D), first R entries written.
 template <typename T, int LOG2D, int K, bool NT>
 __global__ void __launch_bounds__(256)
 wbar_bwd_kernel(T *grad_u, T *part_s1, T *part_s2, const u32x4 *gw, const T *s1, const T *u, const T *s2,
@@ -120,9 +120,10 @@ wbar_bwd_kernel(T *grad_u, T *part_s1, T *part_s2, const u32x4 *gw, const T *s1,
             const A uv = (A)u[(size_t)x.jk * D + x.i];
             const A s2v = (A)s2[(size_t)x.j * D + x.i];
             const A gii = (A)reinterpret_cast<const T *>(gw)[(size_t)row * D + x.i];
-            grad_u[row] = (T)acc_u[n];
-            part_s2[row] = (T)acc_s2[n];
-            part_s1[row] = (T)(gii * ((A)D * (uv * s2v)));
+            const size_t o = (size_t)x.jk * D + x.i;          // outputs are (J, S, D); entries i >= R stay untouched
+            grad_u[o] = (T)acc_u[n];
+            part_s2[o] = (T)acc_s2[n];
+            part_s1[o] = (T)(gii * ((A)D * (uv * s2v)));
         }
     }
 }

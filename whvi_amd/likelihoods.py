@@ -9,6 +9,36 @@ __all__ = ["Likelihood", "GaussianLikelihood"]
 _HALF_LOG_2PI = 0.5 * math.log(2.0 * math.pi)
 
 
+class GaussMNLLFunction(torch.autograd.Function):
+    """``scale * sum log N(y | y_hat, sigma^2)`` over an MC prediction tensor as one HIP reduction
+    (``whvi_gauss_mnll_f32``) with a one-launch closed-form backward; float32 GPU tensors.
+    ``y`` is an expanded view of ``y_hat``'s shape; ``y_hat`` is read (and its gradient written) in its own
+    memory layout, so the ``(batch, out, n_mc)`` permuted view of the batched pass costs no copy."""
+
+    @staticmethod
+    def forward(ctx, y, y_hat, sigma, scale):
+        from whvi_amd import _hip
+        if any(st == 0 and sz > 1 for st, sz in zip(y_hat.stride(), y_hat.size())):
+            y_hat = y_hat.contiguous()                 # expanded predictions: the gradient needs real storage
+        part = _hip.gauss_mnll(y, y_hat, sigma, scale)
+        ctx.save_for_backward(y, y_hat, sigma, part)
+        ctx.scale = float(scale)
+        return part[:, 0].sum()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from whvi_amd import _hip
+        y, y_hat, sigma, part = ctx.saved_tensors
+        if torch.is_grad_enabled():                    # create_graph=True: the closed form as differentiable ops
+            diff = y - y_hat
+            grad_yhat = grad_out * ctx.scale * diff / (sigma * sigma)
+            grad_sigma = grad_out * ctx.scale * ((diff / sigma).square().sum() - diff.numel()) / sigma
+        else:
+            grad_yhat, grad_sigma = _hip.gauss_mnll_bwd(grad_out.contiguous(), part, y, y_hat, sigma, ctx.scale)
+        grad_y = -grad_yhat if ctx.needs_input_grad[0] else None        # autograd sums the expanded axis
+        return grad_y, grad_yhat, grad_sigma, None
+
+
 class Likelihood:
     """Base class: a likelihood that contributes nothing (mean negative log likelihood 0)."""
 
@@ -37,5 +67,9 @@ class GaussianLikelihood(nn.Module, Likelihood):
         batch (m points) to the data set (n points): ``-n / (m * n_mc) * sum`` -- the estimator of
         src/likelihoods.py:18-29, evaluated as one fused reduction instead of a Python loop over outputs."""
         m, n_out, n_mc = y_hat.size()
+        if (y_hat.device.type == "cuda" and y_hat.dtype == y.dtype == self.sigma.dtype == torch.float32
+                and y.device == y_hat.device == self.sigma.device and y_hat.numel() > 0):
+            return GaussMNLLFunction.apply(y.reshape(m, n_out, 1).expand(m, n_out, n_mc), y_hat, self.sigma,
+                                           -n / (m * n_mc))
         total = self.log_density(y.reshape(m, n_out, 1), y_hat).sum()
         return -n / (m * n_mc) * total

@@ -74,12 +74,9 @@ class WBarFunction(torch.autograd.Function):
         from whvi_amd import _hip
         if not torch.is_grad_enabled() and _hip.wbar_bwd_supported(u.dtype, D):
             # first-order backward (the training loop): one launch, grad_W read once (whvi_wbar_bwd)
-            grad_u_r, part_s1, part_s2 = _hip.wbar_bwd(grad_W, s1, u, s2)
-            grad_s1_r, grad_s2_r = part_s1.sum(dim=1), part_s2.sum(dim=1)
-            if R == D:
-                return grad_s1_r, grad_u_r, grad_s2_r, None
-            pad = (0, D - R)
-            return F.pad(grad_s1_r, pad), F.pad(grad_u_r, pad), F.pad(grad_s2_r, pad), None
+            out = _hip.wbar_bwd(grad_W, s1, u, s2)                      # (3, J, S, D): grad_u, per-sample s1 / s2 parts
+            parts = out[1:, :, 0] if S == 1 else out[1:].sum(dim=2)    # one reduction for both scale vectors
+            return parts[0], out[0], parts[1], None
         # create_graph=True (or a shape outside the fused kernel): the same chain as differentiable ops
         fw = fwht_cuda.apply
         with torch.enable_grad():
@@ -105,7 +102,7 @@ class ReparamKLFunction(torch.autograd.Function):
     """``(u, kl) = ReparamKL(g_mu (J, D), g_rho (J, D), eps (J, S, D), lambda)`` in one HIP launch:
     ``u[:, 0] = g_mu``, ``u[:, 1 + k] = softplus(g_rho) * eps[:, k]`` -- the ``b`` operand of the fused weight
     kernel -- and ``kl[j] = kl_diag_normal(g_mu[j], softplus(g_rho[j]), 0, lambda)`` with the reference's argument
-    convention (src/weights.py:52-64, src/utils.py:49-71).  Backward in closed form."""
+    convention (src/weights.py:52-64, src/utils.py:49-71).  Backward: closed form, one launch (``whvi_reparam_kl_bwd``)."""
 
     @staticmethod
     def forward(ctx, g_mu, g_rho, eps, lambda_):
@@ -117,14 +114,19 @@ class ReparamKLFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_u, grad_kl):
+        from whvi_amd import _hip
         g_mu, g_rho, eps, sigma = ctx.saved_tensors
         lam = ctx.lambda_
-        gk = grad_kl.unsqueeze(-1)
-        grad_mu = grad_u[:, 0] + gk * (g_mu / lam)
-        grad_sigma = (grad_u[:, 1:] * eps).sum(dim=1) + gk * (0.5 * (1.0 / lam - 1.0 / sigma))
-        grad_rho = grad_sigma * torch.sigmoid(g_rho)
-        grad_eps = grad_u[:, 1:] * sigma.unsqueeze(1) if ctx.needs_input_grad[2] else None
-        return grad_mu, grad_rho, grad_eps, None
+        grad_eps = grad_u[:, 1:] * sigma.unsqueeze(1) if ctx.needs_input_grad[2] and grad_u is not None else None
+        if not torch.is_grad_enabled():
+            grad_mu, grad_rho = _hip.reparam_kl_bwd(grad_u, grad_kl, g_mu, g_rho, eps, sigma, lam)
+            return grad_mu, grad_rho, grad_eps, None
+        # create_graph=True: the same closed form as differentiable ops
+        gk = (torch.zeros_like(g_mu[:, 0]) if grad_kl is None else grad_kl).unsqueeze(-1)
+        gu = torch.zeros_like(g_mu).unsqueeze(1).expand(-1, eps.shape[1] + 1, -1) if grad_u is None else grad_u
+        grad_mu = gu[:, 0] + gk * (g_mu / lam)
+        grad_sigma = (gu[:, 1:] * eps).sum(dim=1) + gk * (0.5 * (1.0 / lam - 1.0 / sigma))
+        return grad_mu, grad_sigma * torch.sigmoid(g_rho), grad_eps, None
 
 
 def _reparam(g_mu, g_rho, eps, lambda_):
