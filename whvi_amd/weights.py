@@ -129,6 +129,14 @@ class ReparamKLFunction(torch.autograd.Function):
         return grad_mu, grad_sigma * torch.sigmoid(g_rho), grad_eps, None
 
 
+def _mean_plus_rest(t, dim):
+    """``t[0:1] + t[1:]`` along ``dim`` (the ``w_bar(g_mu) + w_bar(g_sigma * eps_k)`` sum of src/weights.py:93), written
+    with ``split``: the same additions, but its backward is one ``cat`` instead of two zero-filled scatter copies
+    and an add over tensors the size of all weight matrices."""
+    mean, rest = t.split((1, t.size(dim) - 1), dim=dim)
+    return mean + rest
+
+
 def _reparam(g_mu, g_rho, eps, lambda_):
     """(u (J, 1+S, D), kl (J,) or None): one fused launch on the GPU when a loss is being built (autograd
     on: the KL of this very pass comes for free and its backward is closed-form); the reference's op chain on
@@ -191,7 +199,7 @@ class WHVISquarePow2Matrix(nn.Module):
     def _w_bar_stack(self, u, rows=None):
         """``w_bar`` for every row of ``u`` (S, D) -> (S, D, D) (first ``rows`` rows on the GPU)."""
         if u.device.type == "cuda":
-            return WBarFunction.apply(self.s1.unsqueeze(0), u.unsqueeze(0), self.s2.unsqueeze(0), rows)[0]
+            return WBarFunction.apply(self.s1.unsqueeze(0), u.unsqueeze(0), self.s2.unsqueeze(0), rows).squeeze(0)
         base = self.fwht(torch.diag(self.s2))
         return torch.stack([matmul_diag_left(self.s1, self.fwht(matmul_diag_left(row, base)))
                             for row in u])
@@ -199,7 +207,7 @@ class WHVISquarePow2Matrix(nn.Module):
     def w_bar(self, u):
         """``S1 . fwht(diag(u) . fwht(diag(s2)))`` (src/weights.py:66-73)."""
         if u.device.type == "cuda":
-            return self._w_bar_stack(u.unsqueeze(0))[0]
+            return self._w_bar_stack(u.unsqueeze(0)).squeeze(0)
         return matmul_diag_left(self.s1, self.fwht(matmul_diag_left(u, self.fwht(torch.diag(self.s2)))))
 
     def sample(self, rows=None):
@@ -208,7 +216,7 @@ class WHVISquarePow2Matrix(nn.Module):
         epsilon = torch.randn(self.D, device=self.g_mu.device)
         g_tilde = self.g_mu + self.g_sigma * epsilon
         if rows is not None and g_tilde.device.type == "cuda":
-            return self._w_bar_stack(g_tilde.unsqueeze(0), rows=rows)[0]
+            return self._w_bar_stack(g_tilde.unsqueeze(0), rows=rows).squeeze(0)
         return self.w_bar(g_tilde)
 
     def _w_bar_diagonal(self, u):
@@ -224,7 +232,7 @@ class WHVISquarePow2Matrix(nn.Module):
             return h * (self._w_bar_diagonal(self.g_mu) + self._w_bar_diagonal(self.g_sigma * epsilon))
         if self.g_mu.device.type == "cuda":
             pair = self._w_bar_stack(torch.stack((self.g_mu, self.g_sigma * epsilon)))
-            return h @ (pair[0] + pair[1]).T
+            return h @ _mean_plus_rest(pair, 0).squeeze(0).T
         return h @ (self.w_bar(self.g_mu) + self.w_bar(self.g_sigma * epsilon)).T
 
     def forward(self, x, use_lrt=True):
@@ -246,13 +254,13 @@ class WHVISquarePow2Matrix(nn.Module):
             out = (x if x.dim() == 3 else x.unsqueeze(0)) * w.unsqueeze(1)
             return out + self.bias if self.bias is not None else out
         u, kl = _reparam(self.g_mu.unsqueeze(0), self.g_rho.unsqueeze(0), eps.unsqueeze(0), self.lambda_)
-        u = u[0]                                                                  # (1 + S, D)
-        self._mc_kl = None if kl is None else kl[0]      # KL of this pass, for WHVINetwork.loss
+        u = u.squeeze(0)                                                          # (1 + S, D)
+        self._mc_kl = None if kl is None else kl.squeeze(0)   # KL of this pass, for WHVINetwork.loss
         if u.device.type == "cuda":
             W = self._w_bar_stack(u)
         else:
             W = torch.stack([self.w_bar(row) for row in u])
-        W = W[0] + W[1:]                                                         # (S, D, D)
+        W = _mean_plus_rest(W, 0)                                                # (S, D, D)
         out = torch.matmul(x, W.transpose(1, 2))                                 # broadcasts a 2-D x
         return out + self.bias if self.bias is not None else out
 
@@ -316,7 +324,7 @@ class WHVIStackedMatrix(nn.Module):
     def sample_lrt(self, h):
         if self._on_gpu():
             W = self._stacked_w_bar(lambda mu, sg, eps: [mu, sg * eps])
-            W = (W[:, 0] + W[:, 1]).reshape(self.stack * self.D_in, self.D_in)   # cat over sub-matrices
+            W = _mean_plus_rest(W, 1).reshape(self.stack * self.D_in, self.D_in)  # cat over sub-matrices
             return h @ W.T
         return torch.cat([weight.sample_lrt(h) for weight in self.weight_matrices], dim=1)
 
@@ -337,7 +345,7 @@ class WHVIStackedMatrix(nn.Module):
             W = WBarFunction.apply(s1, u, s2, None)
         else:
             W = torch.stack([torch.stack([m.w_bar(row) for row in u[j]]) for j, m in enumerate(self.weight_matrices)])
-        W = (W[:, :1] + W[:, 1:]).transpose(0, 1).reshape(S, J * D, D)              # (S, stack*D, D)
+        W = _mean_plus_rest(W, 1).transpose(0, 1).reshape(S, J * D, D)              # (S, stack*D, D)
         x_padded = torch.zeros((*x.size()[:-1], D), device=x.device)
         x_padded[..., :self.n_in] = x
         out = torch.matmul(x_padded, W.transpose(1, 2))
@@ -394,13 +402,13 @@ class WHVIColumnMatrix(nn.Module):
         sq = self.weight_submodule
         eps = torch.randn(n_samples, sq.D, device=sq.g_mu.device)
         u, kl = _reparam(sq.g_mu.unsqueeze(0), sq.g_rho.unsqueeze(0), eps.unsqueeze(0), sq.lambda_)
-        self._mc_kl = None if kl is None else kl[0]
-        g_tilde = u[0, :1] + u[0, 1:]                                               # (S, D_adj): g_mu + g_sigma * eps
+        self._mc_kl = None if kl is None else kl.squeeze(0)
+        g_tilde = _mean_plus_rest(u.squeeze(0), 0)                       # (S, D_adj): g_mu + g_sigma * eps
         if g_tilde.device.type == "cuda":
-            rows0 = sq._w_bar_stack(g_tilde, rows=1)[:, 0]                           # (S, D_adj)
+            rows0 = sq._w_bar_stack(g_tilde, rows=1).squeeze(1)          # (S, D_adj)
         else:
             rows0 = torch.stack([sq.w_bar(g)[0] for g in g_tilde])
-        w = rows0[:, :self.D]                                                        # (S, D)
+        w = rows0 if self.D == sq.D else rows0[:, :self.D]               # (S, D)
         if self.transposed:                       # weight (1, D): out = x . w
             out = (x * w.unsqueeze(1)).sum(dim=-1, keepdim=True)
         else:                                     # weight (D, 1): out = x[..., :1] * w
