@@ -266,11 +266,18 @@ def _extra_layer(device):
     def batched():
         with torch.no_grad():
             return layer.forward_mc(h, 32).sum() + layer.kl
+
+    def train():                              # forward + KL + backward (whvi_wbar_bwd, whvi_reparam_kl_bwd)
+        layer.zero_grad(set_to_none=True)
+        (layer.forward_mc(h, 32).square().mean() + layer.kl).backward()
     ms_loop, ms_batched = event_ms(loop, iters=5, warm=2), event_ms(batched, iters=5, warm=2)
+    ms_train = event_ms(train, iters=5, warm=2)
     return {"loop_ms": round(ms_loop, 3), "loop_ms_per_mc_sample": round(ms_loop / 32, 4),
             "batched_ms": round(ms_batched, 3), "batched_ms_per_mc_sample": round(ms_batched / 32, 4),
+            "batched_fwd_kl_bwd_ms": round(ms_train, 3),
             "modes": "loop = the reference's one forward per MC sample; batched = forward_mc "
-                     "(one fused weight launch + one batched GEMM)"}
+                     "(one fused weight launch + one batched GEMM); fwd_kl_bwd adds the backward pass "
+                     "(one-launch backward of the weight construction; the GEMM gradients dominate)"}
 
 
 def _extra_network(device):

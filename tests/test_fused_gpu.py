@@ -328,8 +328,12 @@ def test_graphed_train_step_learns(hip_lib):
     x = torch.linspace(-1, 1, 64, device=DEV).unsqueeze(1)
     y = torch.sin(3 * x)
     opt = torch.optim.Adam(net.parameters(), lr=1e-2, capturable=True)
+    for _ in range(2):            # the network has already trained eagerly on the default stream ...
+        opt.zero_grad(set_to_none=False)
+        net.loss(x, y, n=64).backward()
+        opt.step()
     before = {k: v.detach().clone() for k, v in net.named_parameters()}
-    step = GraphedTrainStep(net, opt, x, y, n=64)
+    step = GraphedTrainStep(net, opt, x, y, n=64)          # ... and is captured afterwards
     first = float(step(x, y))
     for _ in range(300):
         last = float(step(x, y))

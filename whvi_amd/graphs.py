@@ -10,6 +10,8 @@ torch's generator is graph-aware, so every replay draws fresh eps.
 fused weight kernel runs from the autograd engine's thread and is captured with the rest
 (tools/graph_train_probe.py walks through the stages).
 """
+import gc
+
 import torch
 
 __all__ = ["GraphedPredictor", "GraphedTrainStep"]
@@ -53,9 +55,10 @@ class GraphedTrainStep:
     schedules that change ``lr`` from the host are not captured.  ``x`` / ``y`` keep the example's shapes; the
     returned loss is a static tensor overwritten by the next call.  Fresh eps are drawn on every replay.
 
-    Build it BEFORE any eager ``backward()`` of the network in this process: gradient accumulators created by an
-    earlier backward pass on the default stream make the capture abort inside the HIP runtime (torch warns about an
-    "AccumulateGrad node's stream" mismatch first)."""
+    It may be built after the network has trained eagerly, provided no tensor of an earlier pass that still carries
+    an autograd graph (a kept ``loss``) is alive: gradient accumulators created by a backward pass on another
+    stream make the capture abort inside the HIP runtime (torch warns about an "AccumulateGrad node's stream"
+    mismatch first).  ``WHVINetwork.loss`` itself keeps only detached monitoring values."""
 
     def __init__(self, net, optimizer, example_x, example_y, n: int, ignore_kl: bool = False, warmup: int = 3):
         if example_x.device.type != "cuda":
@@ -66,6 +69,15 @@ class GraphedTrainStep:
         self.net, self.optimizer, self.n, self.ignore_kl = net, optimizer, int(n), bool(ignore_kl)
         self.static_x, self.static_y = example_x.detach().clone(), example_y.detach().clone()
         dev = example_x.device
+        # gradient accumulators of an earlier eager backward belong to the stream that ran it; they die with the
+        # last reference to that pass's autograd graph, so drop ours before warming up on the capture side stream
+        net._pass_kl = None
+        for module in net.modules():
+            if hasattr(module, "_mc_kl"):
+                module._mc_kl = None
+        optimizer.zero_grad(set_to_none=True)
+        gc.collect()
+        torch.cuda.synchronize(dev)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):

@@ -98,10 +98,14 @@ class WHVINetwork(nn.Module, WHVI):
     def loss(self, x, y, n: int, ignore_kl=False) -> torch.Tensor:
         """Negative ELBO estimate = MNLL (+ KL) (src/networks.py:56-69)."""
         self._pass_kl = None
-        self.current_mnll = self.likelihood.mnll_batch_estimate(y, self(x), n)
+        mnll = self.likelihood.mnll_batch_estimate(y, self(x), n)
         pass_kl, self._pass_kl = getattr(self, "_pass_kl", None), None
-        self.current_kl = pass_kl if (pass_kl is not None and not ignore_kl) else self.kl
-        return self.current_mnll if ignore_kl else self.current_mnll + self.current_kl
+        kl = pass_kl if (pass_kl is not None and not ignore_kl) else self.kl
+        # the monitoring attributes of src/networks.py:66-67, kept as detached values: holding the graph tensors
+        # here would keep the whole autograd graph (and its gradient accumulators) alive until the next call
+        self.current_mnll = mnll.detach() if torch.is_tensor(mnll) else mnll
+        self.current_kl = kl.detach() if torch.is_tensor(kl) else kl
+        return mnll if ignore_kl else mnll + kl
 
     def _epochs(self, data_loader, optimizer, scheduler, epochs, label, ignore_kl, pbar_update_period,
                 checkpoint_dir=None, set_to_none=False):
