@@ -380,7 +380,10 @@ fused_shs_kernel(u32x4 *dst, const u32x4 *src, const T *a, const T *b, const T *
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t t = (int64_t)blockIdx.x * (BLOCK / 64) + wave;
+    // streams: XCD-contiguous block order and a block barrier before the stores, as in fwht_rows_kernel
+    int64_t blk = blockIdx.x;
+    if (NT && (gridDim.x & 7) == 0) blk = (blk & 7) * (int64_t)(gridDim.x >> 3) + (blk >> 3);
+    const int64_t t = blk * (BLOCK / 64) + wave;
 
     extern __shared__ __attribute__((aligned(16))) char whvi_smem[];
     // STAGE_AC (AXIS_COL, shared a and c): the block copies the two D-element vectors into LDS once;
@@ -398,7 +401,10 @@ fused_shs_kernel(u32x4 *dst, const u32x4 *src, const T *a, const T *b, const T *
         }
         __syncthreads();
     }
-    if (t >= n_tiles) return;   // (a store-alignment barrier as in fwht_rows_kernel was tried here: neutral)
+    if (t >= n_tiles) {
+        if constexpr (NT) __syncthreads();      // the store-alignment barrier below
+        return;
+    }
 
     auto transform = [&](A (&r)[K][VEC]) {
         if constexpr (POLICY == POLICY_LDS)
@@ -438,19 +444,7 @@ fused_shs_kernel(u32x4 *dst, const u32x4 *src, const T *a, const T *b, const T *
     // trips hide under ~1500 butterfly instructions each instead of stalling the wave three times.
     A r[K][VEC];
     A sc[K][VEC];                      // the one scale vector in flight (AXIS_COL) / row scalars
-    auto fetch_scale = [&](const T *vec, bool per_sample, const A *staged = nullptr) {
-        if constexpr (STAGE_AC) {
-            if (staged != nullptr) {
-                typedef A vec4 __attribute__((ext_vector_type(4)));
-#pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    const vec4 v = *reinterpret_cast<const vec4 *>(staged + chunk_col(k) * VEC);
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) sc[k][e] = v[e];
-                }
-                return;
-            }
-        }
+    auto fetch_scale = [&](const T *vec, bool per_sample) {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             uint32_t vec_base = 0;
@@ -466,6 +460,18 @@ fused_shs_kernel(u32x4 *dst, const u32x4 *src, const T *a, const T *b, const T *
             for (int e = 0; e < VEC; ++e) r[k][e] = sc[k][e] * r[k][e];
     };
 
+    // shared a / c staged in LDS: multiply straight out of LDS, chunk by chunk -- no 64-register copy of the
+    // vector is ever live (the per-sample vector b is the only one held in registers across a transform)
+    auto apply_staged = [&](const A *staged) {
+        typedef A vec4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const vec4 v = *reinterpret_cast<const vec4 *>(staged + chunk_col(k) * VEC);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) r[k][e] = v[e] * r[k][e];
+        }
+    };
+
     // ---- load (or synthesise) + first scale
     if constexpr (EYE) {
 #pragma unroll
@@ -478,22 +484,55 @@ fused_shs_kernel(u32x4 *dst, const u32x4 *src, const T *a, const T *b, const T *
         }
     } else {
         u32x4 raw[K];
+        if (full) {
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            u32x4 z = {0u, 0u, 0u, 0u};
-            raw[k] = chunk_ok(k) ? ld16<NT>(src + base + k * 64 + lane) : z;
+            for (int k = 0; k < K; ++k) raw[k] = ld16<NT>(src + base + k * 64 + lane);
+        } else {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                u32x4 z = {0u, 0u, 0u, 0u};
+                raw[k] = (base + k * 64 + lane < n_chunks) ? ld16<NT>(src + base + k * 64 + lane) : z;
+            }
         }
-        if (c != nullptr) fetch_scale(c, c_per_sample, STAGE_AC ? lds_c : nullptr);
+        if constexpr (STAGE_AC) {
 #pragma unroll
-        for (int k = 0; k < K; ++k) E::unpack(raw[k], r[k]);
-        if (c != nullptr) apply_scale();
+            for (int k = 0; k < K; ++k) E::unpack(raw[k], r[k]);
+            if (c != nullptr) apply_staged(lds_c);
+        } else {
+            if (c != nullptr) fetch_scale(c, c_per_sample);
+#pragma unroll
+            for (int k = 0; k < K; ++k) E::unpack(raw[k], r[k]);
+            if (c != nullptr) apply_scale();
+        }
     }
-    if (b != nullptr) fetch_scale(b, true);
-    transform(r);
-    if (b != nullptr) apply_scale();
-    if (a != nullptr) fetch_scale(a, a_per_sample, STAGE_AC ? lds_a : nullptr);
-    transform(r);
-    if (a != nullptr) apply_scale();
+    if constexpr (STAGE_AC) {
+        // per-sample vector: fetched from L2 after the first transform and consumed chunk by chunk (the
+        // scheduler keeps as many loads in flight as the 128-VGPR budget allows); holding all of it across the
+        // transform cost a whole wave of occupancy per SIMD
+        transform(r);
+        if (b != nullptr) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                A v[VEC];
+                scale(b, sample_index(chunk_row(k)) * (1u << LOG2D), k, v);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) r[k][e] = v[e] * r[k][e];
+            }
+        }
+    } else {
+        if (b != nullptr) fetch_scale(b, true);
+        transform(r);
+        if (b != nullptr) apply_scale();
+    }
+    if constexpr (STAGE_AC) {
+        transform(r);
+        if (a != nullptr) apply_staged(lds_a);
+    } else {
+        if (a != nullptr) fetch_scale(a, a_per_sample);
+        transform(r);
+        if (a != nullptr) apply_scale();
+    }
+    if constexpr (NT) __syncthreads();          // the block's 4 waves write their 64 KiB back together
     if (NT && full) {
 #pragma unroll
         for (int k = 0; k < K; ++k) tile_store_stream(dst + base, lane, k, E::pack(r[k]), TILE * 16);
