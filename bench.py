@@ -233,7 +233,7 @@ def _extra_f16(device):
     """BASELINE config 5 (one GPU's share): D = 4096 fp16, 2^20 rows = 8 GiB."""
     from whvi_amd import _hip
     x = (torch.randn(1 << 20, 4096, device=device) * 2.0 ** -8).half()
-    return _rate(1 << 20, 4096, 2, event_ms(lambda: _hip.fwht_rows(x, out=x), iters=6))
+    return _rate(1 << 20, 4096, 2, event_ms(lambda: _hip.fwht_rows(x, out=x), iters=10, warm=10))
 
 
 def _extra_fused(device):
@@ -243,7 +243,7 @@ def _extra_fused(device):
     x = torch.randn(B * S, d, device=device)
     a, c = torch.randn(d, device=device) * 0.01, torch.randn(d, device=device) * 0.01
     g = torch.randn(S, d, device=device)
-    ms = event_ms(lambda: _hip.fused_shs(x, a, g, c, axis="col", n_samples=S, sample_stride=1, out=x), iters=6)
+    ms = event_ms(lambda: _hip.fused_shs(x, a, g, c, axis="col", n_samples=S, sample_stride=1, out=x), iters=20, warm=30)   # clocks take ~25 launches to ramp
     res = _rate(B * S, d, 4, ms)
     res["note"] = ("one fused launch = 2 FWHTs + 3 scalings per row; unfused (2 FWHT launches + 3 elementwise) "
                    "moves 5x the bytes")
