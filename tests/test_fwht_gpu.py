@@ -153,6 +153,26 @@ def test_production_launch_geometries(dtype, log2d, rows, hip_lib):
     assert torch.equal(fx[idx].cpu().view(torch.uint8), _oracle(x[idx].cpu()).view(torch.uint8))
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("log2d,rows", [(12, 40000), (10, 150001), (7, 1200003), (3, 17000001)])
+def test_streaming_launch_of_16bit_types(dtype, log2d, rows, hip_lib):
+    """Streams >= 256 MiB of fp16 / bf16 take the LDS-staged butterfly network (256-thread blocks, block barrier
+    before the non-temporal stores), incl. a partial last tile: every row bit-identical to the ds_bpermute
+    cross-check network (whvi_fwht_ex variant 1) and to f32 arithmetic + one rounding; in place == out of place."""
+    d = 1 << log2d
+    g = torch.Generator(device=DEV).manual_seed(log2d)
+    x = (torch.randn(rows, d, generator=g, device=DEV) * 0.25).to(dtype)
+    assert x.numel() * x.element_size() >= 256 << 20
+    got = _hip.fwht_rows(x)
+    assert torch.equal(got.view(torch.int16), _hip.fwht_rows(x, variant=1).view(torch.int16))
+    idx = torch.tensor([0, 1, rows // 3, rows - 2, rows - 1], device=DEV)
+    assert torch.equal(got[idx].view(torch.int16), _hip.fwht_rows(x[idx].float()).to(dtype).view(torch.int16))
+    assert torch.equal(got[idx].cpu().view(torch.int16), _oracle(x[idx].cpu()).view(torch.int16))
+    keep = got.clone()
+    _hip.fwht_rows(x, out=x)
+    assert torch.equal(x.view(torch.int16), keep.view(torch.int16))
+
+
 def test_headline_size_in_place_involution(hip_lib):
     """The bench workload itself (D = 4096, 2^20 rows = 16 GiB, > 2^32 bytes of offsets, in place,
     non-temporal 1024-thread launch): H.H = 4096.I exactly on small integers, plus oracle rows."""

@@ -115,6 +115,13 @@ inline void launch_rows(void *dst, const void *src, int64_t n_chunks, int varian
                 // 6.2, bf16 5.0 -> 6.1, i32 5.8 -> 6.3 TB/s (tools/probe_stream_blocks.py)
                 static const bool exp_big_blocks = getenv("WHVI_STREAM_BIG_BLOCKS") != nullptr;   // A/B switch
                 if (exp_big_blocks || sizeof(T) == 8) WHVI_LAUNCH(POLICY_DPP, false, true, BIG);   // f64: 6.0 vs 5.8
+                else if constexpr (sizeof(T) == 2 && K * Elem<T>::VEC == 64)
+                    // 16-bit storage: half the bytes per butterfly, so the DPP network's VALU time co-limits the
+                    // stream (6.1 TB/s).  The LDS-staged network needs a third of the issue slots: fp16 6.4,
+                    // bf16 6.5 TB/s (tools/probe_f16.py), even at 8 waves per CU (16.6 KB of LDS per wave).
+                    hipLaunchKernelGGL((fwht_rows_kernel<T, LOG2D, K, POLICY_LDS, false, true, 256, 1>),
+                                       dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), (size_t)4 * rows_slab_bytes, st,
+                                       d, s, n_chunks, n_tiles);
                 else
                     hipLaunchKernelGGL((fwht_rows_kernel<T, LOG2D, K, POLICY_DPP, false, true, 256, 1>),
                                        dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, st, d, s, n_chunks, n_tiles);
@@ -144,7 +151,11 @@ inline void launch_rows(void *dst, const void *src, int64_t n_chunks, int varian
             break;
         case 7:
             if constexpr (sizeof(typename Elem<T>::acc) == 4 && K * Elem<T>::VEC == 64) {
-                if (blk == 0) WHVI_LAUNCH(POLICY_LDS, false, true, 256);
+                if (blk == 0 && ((variant >> 6) & 3) != 0 && bpc == 0)
+                    hipLaunchKernelGGL((fwht_rows_kernel<T, LOG2D, K, POLICY_LDS, false, true, 256, 1>),
+                                       dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), (size_t)4 * rows_slab_bytes, st,
+                                       d, s, n_chunks, n_tiles);
+                else if (blk == 0) WHVI_LAUNCH(POLICY_LDS, false, true, 256);
                 else if (blk == 1) WHVI_LAUNCH(POLICY_LDS, false, true, 512);
                 else WHVI_LAUNCH(POLICY_LDS, false, true, 576);
             }
