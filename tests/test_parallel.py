@@ -104,3 +104,6 @@ def test_bench_two_ranks_gloo_cpu_plumbing(tmp_path):
     assert len(lines) == 1, out.stdout
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
+    # the N > 1 extras: MC-sharded network pass with one all-gather (tiny sizes in plumbing mode)
+    sharded = rec["extras_multi_gpu"]["whviregression_3_1024_1024_1_mc128_sharded"]
+    assert sharded["prediction_shape"] == [16, 1, 4] and sharded["mc_samples_per_gpu"] == 2 and sharded["ms"] > 0

@@ -28,5 +28,9 @@ assert pred.shape == (7, 1, 6)
 net.loss(torch.randn(7, 3, device=dev), torch.randn(7, 1, device=dev), 70).backward()
 parallel.all_reduce_grads(net)
 torch.cuda.synchronize()
+# bench.py's N > 1 extras (fp16 row shards, MC-sharded network pass with one all-gather) at their real sizes
+import json
+import bench
+print(json.dumps(bench.multi_gpu_extras(dev, 0, 1)), flush=True)
 dist.destroy_process_group()
 print("nccl one-rank paths ok", float(t))
