@@ -463,3 +463,48 @@ def test_gauss_mnll_kernel_vs_reference_formula(m, n_out, n_mc, layout, hip_lib)
     assert abs(float(got) - float(want)) <= 2e-5 * abs(float(want))
     assert float((g_base.double() - w_base).abs().max()) <= 2e-5 * float(w_base.abs().max())
     assert abs(float(g_sigma) - float(w_sigma)) <= 5e-5 * abs(float(w_sigma))
+
+
+@pytest.mark.parametrize("n_in,n_out", [(8, 8), (64, 64), (512, 512), (3, 16), (5, 7), (13, 128), (100, 33), (4, 1024),
+                                        (1, 10), (1, 128), (16, 1), (100, 1), (2, 2), (2, 5), (1, 1)])
+def test_layer_gradients_gpu_vs_host_path(n_in, n_out, monkeypatch, hip_lib):
+    """Every WHVILinear flavour (square / stacked / column / transposed column): forward output and ALL gradients
+    (s1, s2, g_mu, g_rho, bias, input) on the GPU -- fused weight kernel, one-launch backward kernels -- against the
+    host path, which runs the reference's op chain under plain autograd (src/weights.py:34-41,66-93), with the
+    same parameters and the same eps.  North-star tolerance: 1e-5 relative (3e-5 on gradients, whose host
+    values carry the dense-H matmul's own rounding)."""
+    import copy
+    torch.manual_seed(n_in * 1009 + n_out)
+    host = WHVILinear(n_in, n_out, lambda_=0.5, bias=True)
+    with torch.no_grad():
+        for name, p in host.named_parameters():
+            if name.endswith("g_mu") or name.endswith("bias"):
+                p.copy_(torch.randn(p.shape) * 0.3)
+            if name.endswith("s1") or name.endswith("s2"):
+                p.mul_(30.0)
+    dev = copy.deepcopy(host).to(DEV)
+    sub = host.weight_submodule
+    if hasattr(sub, "weight_matrices"):
+        n_draws, d_eps = sub.stack, sub.D_in
+    elif hasattr(sub, "weight_submodule"):
+        n_draws, d_eps = 1, sub.weight_submodule.D
+    else:
+        n_draws, d_eps = 1, sub.D
+    eps = [np.random.default_rng(31 + i).standard_normal(d_eps).astype(np.float32) for i in range(n_draws)]
+    x = torch.randn(11, n_in)
+    w = torch.randn(11, n_out)
+    results = []
+    for layer, device in ((host, "cpu"), (dev, DEV)):
+        xin = x.detach().clone().to(device).requires_grad_()
+        monkeypatch.setattr(torch, "randn", ReplayRandn(eps))
+        out = layer(xin)
+        monkeypatch.undo()
+        ((out * w.to(device)).sum() + layer.kl).backward()
+        grads = {k: p.grad.detach().cpu() for k, p in layer.named_parameters()}
+        grads["input"] = xin.grad.detach().cpu()
+        results.append((out.detach().cpu(), grads))
+    (out_h, g_h), (out_d, g_d) = results
+    assert float((out_h - out_d).abs().max()) <= 1e-5 * max(float(out_h.abs().max()), 1e-30)
+    for k in g_h:
+        scale = max(float(g_h[k].abs().max()), 1e-30)
+        assert float((g_h[k] - g_d[k]).abs().max()) <= 3e-5 * scale, k
