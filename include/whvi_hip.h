@@ -157,21 +157,38 @@ int whvi_reparam_kl_blocks(int64_t D);
 int whvi_reparam_kl_f32(void *u, void *sigma, void *kl_part, const void *g_mu, const void *g_rho,
                         const void *eps, int64_t J, int64_t S, int64_t D, float lambda_, void *stream);
 
-/* Backward of the weight construction W[j,k] = S1_j . fwht(diag(u[j,k]) . fwht(diag(s2_j))) (src/weights.py:73)
- * in ONE launch: reads the incoming gradient once, writes three scalars per row.  The reference obtains the
- * same quantities from autograd over its op chain (matmul_diag_left backward, src/utils.py:4-12, and
- * FWHTFunction.backward = FWHT, src/fwht/cuda/fwht.py:14-16): four more FWHT launches and ~10 elementwise /
- * reduction launches over (J, S, R, D) tensors.  Buffers, all of the entry point's dtype, contiguous:
+/* The weight construction itself as a dedicated launch (src/weights.py:73; the generic route is
+ * whvi_fused_shs_ex with src == NULL -- same bits):
+ *     dst[j,k,i,:] = s1[j,i] * fwht( u[j,k,i] * fwht(s2[j,i] e_i) )  (+ base[j,i,:])
+ * for the first R <= D rows i of each of the J x S matrices.  fwht(s2_i e_i) = s2_i H[i,:] is generated from bit
+ * parities (the butterflies of a one-hot row are exact), so each row costs ONE transform, no HBM read, one write.
+ * `base` (J, R, D), optional: a matrix added to every sample's matrix in the epilogue -- with base =
+ * w_bar(g_mu) from a first call this is `w_bar(g_mu) + w_bar(g_sigma * eps_k)` of src/weights.py:93 without a
+ * separate read-modify-write pass over all weight matrices.
+ *   s1, s2 : (J, D)     u : (J, S, D)     dst : (J, S, R, D)     log2d in [2, 13] (f32) / [1, 12] (f64) */
+int whvi_wbar_fwd_f32(void *dst, const void *s1, const void *u, const void *s2, const void *base,
+                      int64_t J, int64_t S, int64_t R, int32_t log2d, void *stream);
+int whvi_wbar_fwd_f64(void *dst, const void *s1, const void *u, const void *s2, const void *base,
+                      int64_t J, int64_t S, int64_t R, int32_t log2d, void *stream);
+
+/* Backward of the weight construction in ONE launch: reads the incoming gradient once, writes three scalars per
+ * row.  The reference obtains the same quantities from autograd over its op chain (matmul_diag_left backward,
+ * src/utils.py:4-12, and FWHTFunction.backward = FWHT, src/fwht/cuda/fwht.py:14-16): four more FWHT launches and
+ * ~10 elementwise / reduction launches over (J, S, R, D) tensors.  Buffers of the entry point's dtype, contiguous:
  *   grad_w  : (J, S, R, D)  dL/dW, first R <= D rows of every matrix      s1, s2 : (J, D)      u : (J, S, D)
  *   grad_u  : (J, S, D)     dL/du[j,k,i] for i < R; entries i >= R are NOT written (zero-fill them when R < D)
  *   part_s1 : (J, S, D)     per-sample contributions, same convention; dL/ds1[j,i] = sum over k (likewise part_s2)
+ * flags = WHVI_WBAR_MEAN: W[j,k] = w_bar(u[j,0]) + w_bar(u[j,1+k]) (the whvi_wbar_fwd `base` form): u and the three
+ *   outputs are (J, 1 + S, D); rows 1..S are written (part_s1 / part_s2 include the mean vector's share) and row 0 is
+ *   left to the caller: the sum over k of rows 1..S is dL/du[j,0] resp. the per-matrix totals.
  * log2d in [2, 13] (f32) / [1, 12] (f64). */
+#define WHVI_WBAR_MEAN 1
 int whvi_wbar_bwd_f32(void *grad_u, void *part_s1, void *part_s2, const void *grad_w, const void *s1,
                       const void *u, const void *s2, int64_t J, int64_t S, int64_t R, int32_t log2d,
-                      void *stream);
+                      int32_t flags, void *stream);
 int whvi_wbar_bwd_f64(void *grad_u, void *part_s1, void *part_s2, const void *grad_w, const void *s1,
                       const void *u, const void *s2, int64_t J, int64_t S, int64_t R, int32_t log2d,
-                      void *stream);
+                      int32_t flags, void *stream);
 
 /* Backward of whvi_reparam_kl_f32 in one launch (closed form): grad_u (J, 1+S, D) and grad_kl (J) are the incoming
  * gradients (either may be NULL = zero), sigma the forward's saved output; writes grad_mu, grad_rho (J, D).

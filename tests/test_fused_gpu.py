@@ -508,3 +508,57 @@ def test_layer_gradients_gpu_vs_host_path(n_in, n_out, monkeypatch, hip_lib):
     for k in g_h:
         scale = max(float(g_h[k].abs().max()), 1e-30)
         assert float((g_h[k] - g_d[k]).abs().max()) <= 3e-5 * scale, k
+
+
+@pytest.mark.parametrize("dtype,J,S,D,R", [
+    (torch.float32, 1, 1, 4, 4), (torch.float32, 1, 3, 8, 8), (torch.float32, 3, 2, 16, 5), (torch.float32, 2, 2, 64, 64),
+    (torch.float32, 1, 5, 128, 128), (torch.float32, 2, 3, 512, 512), (torch.float32, 1, 2, 1024, 1000),
+    (torch.float32, 1, 2, 4096, 4096), (torch.float32, 1, 2, 8192, 24), (torch.float32, 256, 2, 4, 4), (torch.float32, 5, 1, 32, 1),
+    (torch.float64, 1, 2, 2, 2), (torch.float64, 2, 2, 4, 3), (torch.float64, 1, 2, 128, 128), (torch.float64, 1, 1, 4096, 9)])
+def test_wbar_forward_kernel_bit_identical_to_generic_fused_launch(dtype, J, S, D, R, hip_lib):
+    """whvi_wbar_fwd (first transform generated from bit parities, optional mean-matrix add) against the generic
+    fused launch with the identity input (two real transforms) and a separate torch add: bit for bit, and against
+    the CPU oracle's pipeline on the first matrix."""
+    g = torch.Generator().manual_seed(J * 77 + D + R)
+    s1, s2 = (torch.randn(J, D, generator=g, dtype=dtype).to(DEV) for _ in range(2))
+    u = torch.randn(J, S, D, generator=g, dtype=dtype).to(DEV)
+    got = _hip.wbar_fwd(s1, u, s2, R)
+    ref = _hip.fused_shs(None, a=s1[:, :R].repeat_interleave(S, dim=0), b=u[:, :, :R], c=s2[:, :R].repeat_interleave(S, dim=0),
+                         axis="row", n_samples=J * S, sample_stride=R, group_rows=R, rows=J * S * R, d=D, dtype=dtype,
+                         device=torch.device(DEV), a_per_sample=True, c_per_sample=True).view(J, S, R, D)
+    assert got.shape == (J, S, R, D)
+    assert torch.equal(got.view(torch.uint8), ref.view(torch.uint8))
+    npdt = np.float32 if dtype == torch.float32 else np.float64
+    eye = np.eye(D, dtype=npdt)[:R]
+    want = oracle.pipeline(eye, s1[0, :R].cpu().numpy(), u[0, :1, :R].cpu().numpy(), s2[0, :R].cpu().numpy(),
+                           n_samples=1, sample_stride=R, group_rows=R, axis="row")
+    assert np.array_equal(_bits(got[0, 0].cpu().numpy()), _bits(want))
+    # mean-matrix add in the epilogue == a separate add of separately rounded matrices
+    base = torch.randn(J, R, D, generator=g, dtype=dtype).to(DEV)
+    with_base = _hip.wbar_fwd(s1, u, s2, R, base=base)
+    assert torch.equal(with_base.view(torch.uint8), (base.unsqueeze(1) + got).view(torch.uint8))
+
+
+@pytest.mark.parametrize("dtype,J,S,D,R", [
+    (torch.float32, 1, 1, 8, 8), (torch.float32, 2, 3, 64, 64), (torch.float32, 3, 2, 16, 5), (torch.float32, 1, 4, 512, 512),
+    (torch.float32, 1, 1, 4096, 100), (torch.float32, 1, 2, 2, 2), (torch.float64, 2, 2, 128, 128), (torch.float64, 1, 3, 4, 3)])
+def test_wbar_mean_plus_forward_and_backward(dtype, J, S, D, R, hip_lib):
+    """``mean_plus``: W[j,k] = w_bar(u[j,0]) + w_bar(u[j,1+k]) from two launches, bit-identical to building all
+    1 + S matrices and adding; its one-launch backward (WHVI_WBAR_MEAN) against the differentiable op chain."""
+    g = torch.Generator().manual_seed(J * 31 + D + R)
+    s1, s2 = (torch.randn(J, D, generator=g, dtype=dtype).to(DEV).requires_grad_() for _ in range(2))
+    u = torch.randn(J, S + 1, D, generator=g, dtype=dtype).to(DEV).requires_grad_()
+    gw = torch.randn(J, S, R, D, generator=g, dtype=dtype).to(DEV)
+    rows = None if R == D else R
+    W = WBarFunction.apply(s1, u, s2, rows, True)
+    every = WBarFunction.apply(s1, u, s2, rows)
+    assert W.shape == (J, S, R, D)
+    assert torch.equal(W.view(torch.uint8), (every[:, :1] + every[:, 1:]).view(torch.uint8))
+    fused = torch.autograd.grad(W, (s1, u, s2), gw)
+    W = WBarFunction.apply(s1, u, s2, rows, True)
+    chain = torch.autograd.grad(W, (s1, u, s2), gw, create_graph=True)
+    tol = 2e-6 if dtype == torch.float32 else 1e-13
+    for name, a, b in zip(("s1", "u", "s2"), fused, chain):
+        b = b.detach()
+        assert a.shape == b.shape, name
+        assert float((a - b).abs().max()) <= tol * (float(b.abs().max()) or 1.0) * math.sqrt(D) * (S + 1), name

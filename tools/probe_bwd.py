@@ -58,3 +58,19 @@ for mode in ("kernel", "chain"):
     _hip.wbar_bwd_supported = supported if mode == "kernel" else (lambda *a: False)
     print(f"WHVILinear(512,512) forward_mc(32) + backward, batch 4096 [{mode}]: {timed(layer_step, 20):.3f} ms", flush=True)
 _hip.wbar_bwd_supported = supported
+
+big = WHVILinear(4096, 4096).to(dev)
+xs = torch.randn(64, 4096, device=dev)
+
+
+def big_fwd():
+    with torch.no_grad():
+        big.forward_mc(xs, 8)
+
+
+def big_step():
+    big.zero_grad(set_to_none=True)
+    (big.forward_mc(xs, 8).square().mean() + big.kl).backward()
+
+
+print(f"WHVILinear(4096,4096) forward_mc(8), batch 64: forward {timed(big_fwd, 20):.3f} ms, forward+backward {timed(big_step, 20):.3f} ms", flush=True)

@@ -75,7 +75,10 @@ def _declare_f3(lib):
     for sfx in ("f32", "f64"):
         fn = getattr(lib, "whvi_wbar_bwd_" + sfx)
         fn.restype = ctypes.c_int
-        fn.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, ctypes.c_int32, vp]
+        fn.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, ctypes.c_int32, ctypes.c_int32, vp]
+        fn = getattr(lib, "whvi_wbar_fwd_" + sfx)
+        fn.restype = ctypes.c_int
+        fn.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, ctypes.c_int32, vp]
 
 
 def lib():
@@ -263,23 +266,47 @@ def wbar_bwd_supported(dtype: torch.dtype, d: int) -> bool:
     return dtype == torch.float64 and 2 <= d <= 4096
 
 
-def wbar_bwd(grad_w: torch.Tensor, s1: torch.Tensor, u: torch.Tensor, s2: torch.Tensor):
-    """One launch: a (3, J, S, D) tensor [grad_u, part_s1, part_s2] from grad_w (J, S, R, D), s1 / s2 (J, D) and
-    u (J, S, D); entries i >= R are zero.  See whvi_wbar_bwd_f32 in include/whvi_hip.h."""
+def wbar_fwd(s1: torch.Tensor, u: torch.Tensor, s2: torch.Tensor, rows: int = None, base: torch.Tensor = None):
+    """One launch: W (J, S, R, D) with W[j,k] = the first R rows of S1_j fwht(diag(u[j,k]) fwht(diag(s2_j))), plus
+    ``base`` (J, R, D) when given; see whvi_wbar_fwd_f32 in include/whvi_hip.h."""
+    if u.device.type != "cuda" or u.dtype not in (torch.float32, torch.float64):
+        raise RuntimeError("wbar_fwd: float32 / float64 CUDA tensors only")
+    J, S, D = u.shape
+    R = D if rows is None else int(rows)
+    if tuple(s1.shape) != (J, D) or tuple(s2.shape) != (J, D) or (base is not None and tuple(base.shape) != (J, R, D)):
+        raise RuntimeError("wbar_fwd: operand shapes do not match u")
+    if not (s1.dtype == s2.dtype == u.dtype) or (base is not None and base.dtype != u.dtype):
+        raise RuntimeError("wbar_fwd: operand dtypes do not match u")
+    s1, u, s2 = s1.contiguous(), u.contiguous(), s2.contiguous()
+    base = None if base is None else base.contiguous()
+    out = torch.empty((J, S, R, D), dtype=u.dtype, device=u.device)
+    fn = getattr(lib(), "whvi_wbar_fwd_" + _DTYPE_SUFFIX[u.dtype])
+    with _OnDevice(u.device):
+        rc = fn(out.data_ptr(), s1.data_ptr(), u.data_ptr(), s2.data_ptr(), None if base is None else base.data_ptr(),
+                J, S, R, D.bit_length() - 1, _stream(u))
+    _check(rc, "whvi_wbar_fwd")
+    return out
+
+
+def wbar_bwd(grad_w: torch.Tensor, s1: torch.Tensor, u: torch.Tensor, s2: torch.Tensor, mean: bool = False):
+    """One launch: a (3, J, U, D) tensor [grad_u, part_s1, part_s2] from grad_w (J, S, R, D), s1 / s2 (J, D) and
+    u (J, U, D), U = S -- or 1 + S with ``mean`` (W[j,k] = w_bar(u[j,0]) + w_bar(u[j,1+k]); slot 0 of the result is
+    then left for the caller's sum over slots 1..S).  Entries i >= R are zero.  See whvi_wbar_bwd_f32."""
     if grad_w.device.type != "cuda" or grad_w.dtype not in (torch.float32, torch.float64):
         raise RuntimeError("wbar_bwd: float32 / float64 CUDA tensors only")
     J, S, R, D = grad_w.shape
-    if tuple(u.shape) != (J, S, D) or tuple(s1.shape) != (J, D) or tuple(s2.shape) != (J, D):
+    U = S + 1 if mean else S
+    if tuple(u.shape) != (J, U, D) or tuple(s1.shape) != (J, D) or tuple(s2.shape) != (J, D):
         raise RuntimeError("wbar_bwd: operand shapes do not match grad_w")
     if not (u.dtype == s1.dtype == s2.dtype == grad_w.dtype):
         raise RuntimeError("wbar_bwd: operand dtypes do not match grad_w")
     grad_w, s1, u, s2 = grad_w.contiguous(), s1.contiguous(), u.contiguous(), s2.contiguous()
     alloc = torch.empty if R == D else torch.zeros
-    out = alloc((3, J, S, D), dtype=grad_w.dtype, device=grad_w.device)
+    out = alloc((3, J, U, D), dtype=grad_w.dtype, device=grad_w.device)
     fn = getattr(lib(), "whvi_wbar_bwd_" + _DTYPE_SUFFIX[grad_w.dtype])
     with _OnDevice(grad_w.device):
         rc = fn(out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), grad_w.data_ptr(), s1.data_ptr(),
-                u.data_ptr(), s2.data_ptr(), J, S, R, D.bit_length() - 1, _stream(grad_w))
+                u.data_ptr(), s2.data_ptr(), J, S, R, D.bit_length() - 1, 1 if mean else 0, _stream(grad_w))
     _check(rc, "whvi_wbar_bwd")
     return out
 

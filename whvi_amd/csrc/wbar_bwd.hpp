@@ -21,8 +21,9 @@ namespace whvi {
 template <typename A> __device__ __forceinline__ A flip_if(A v, bool neg) { return neg ? -v : v; }
 
 // Tile ownership and index helpers as in fused_shs_kernel.  Rows are (J, S, R) x D, s1 / s2 are (J, D),
-// u is (J, S, D) (only the first R entries of each are used); outputs are (J, S, D), first R entries written.
-template <typename T, int LOG2D, int K, bool NT>
+// u is (J, S, D) -- or (J, 1 + S, D) with MEAN, row 0 of each j being the mean vector added to every sample's
+// matrix -- and the outputs are laid out like u (first R entries of rows 1.. written; MEAN leaves row 0 to the caller's sum).
+template <typename T, int LOG2D, int K, bool NT, bool MEAN>
 __global__ void __launch_bounds__(256)
 wbar_bwd_kernel(T *grad_u, T *part_s1, T *part_s2, const u32x4 *gw, const T *s1, const T *u, const T *s2,
                 int64_t n_chunks, int64_t n_tiles, uint32_t n_rows, FastDiv by_r, FastDiv by_s)
@@ -57,12 +58,14 @@ wbar_bwd_kernel(T *grad_u, T *part_s1, T *part_s2, const u32x4 *gw, const T *s1,
     };
     auto chunk_col = [&](int k) -> uint32_t { return (uint32_t)(k * 64 + lane) & (CPR - 1); };
     // scalar operands of a row; rows past the end read row 0's (valid memory, results discarded)
-    struct RowIdx { uint32_t i, jk, j; };   // row i of matrix (j, k); jk = j * S + k
+    struct RowIdx { uint32_t i, jk, j, ur, u0; };   // row i of matrix (j, k); jk = j * S + k; ur / u0: rows of u
     auto row_index = [&](uint32_t row) -> RowIdx {
         const uint32_t rr = row < n_rows ? row : 0u;
         const uint32_t jk = by_r.div(rr);
         const uint32_t i = rr - jk * by_r.d;
-        return RowIdx{i, jk, by_s.div(jk)};
+        const uint32_t j = by_s.div(jk);
+        // MEAN: u is (J, 1 + S, D) = [u_mean; u_1 .. u_S] and W[j,k] = w_bar(u_mean) + w_bar(u_k)
+        return RowIdx{i, jk, j, MEAN ? jk + j + 1 : jk, MEAN ? j * by_s.d + j : 0u};
     };
 
     A r[K][VEC];
@@ -88,7 +91,8 @@ wbar_bwd_kernel(T *grad_u, T *part_s1, T *part_s2, const u32x4 *gw, const T *s1,
 #pragma unroll
     for (int n = 0; n < NACC; ++n) {
         const RowIdx x = row_index(chunk_row(n * KPR));
-        const A uv = (A)u[(size_t)x.jk * D + x.i];
+        const A uv = (A)u[(size_t)x.ur * D + x.i];
+        const A uv0 = MEAN ? (A)u[(size_t)x.u0 * D + x.i] : (A)0;
         const A s2v = (A)s2[(size_t)x.j * D + x.i];
         A su = (A)0, ss = (A)0;
 #pragma unroll
@@ -100,6 +104,7 @@ wbar_bwd_kernel(T *grad_u, T *part_s1, T *part_s2, const u32x4 *gw, const T *s1,
                 const bool neg = __builtin_popcount(x.i & (dbase + e)) & 1;        // H[i,d] = -1
                 su += flip_if(r[k][e] * s2v, neg);
                 ss += flip_if(uv * r[k][e], neg);
+                if constexpr (MEAN) ss += flip_if(uv0 * r[k][e], neg);
             }
         }
 #pragma unroll
@@ -117,20 +122,22 @@ wbar_bwd_kernel(T *grad_u, T *part_s1, T *part_s2, const u32x4 *gw, const T *s1,
         const bool writer = (SH >= 6) ? (lane == 0) : ((lane & (int)(CPR - 1)) == 0);
         if (writer && row < n_rows) {
             const RowIdx x = row_index(row);
-            const A uv = (A)u[(size_t)x.jk * D + x.i];
+            const A uv = (A)u[(size_t)x.ur * D + x.i];
             const A s2v = (A)s2[(size_t)x.j * D + x.i];
             const A gii = (A)reinterpret_cast<const T *>(gw)[(size_t)row * D + x.i];
-            const size_t o = (size_t)x.jk * D + x.i;          // outputs are (J, S, D); entries i >= R stay untouched
+            const size_t o = (size_t)x.ur * D + x.i;          // outputs are laid out like u; entries i >= R stay untouched
+            A p1 = gii * ((A)D * (uv * s2v));
+            if constexpr (MEAN) p1 += gii * ((A)D * ((A)u[(size_t)x.u0 * D + x.i] * s2v));
             grad_u[o] = (T)acc_u[n];
             part_s2[o] = (T)acc_s2[n];
-            part_s1[o] = (T)(gii * ((A)D * (uv * s2v)));
+            part_s1[o] = (T)p1;
         }
     }
 }
 
 template <typename T, int LOG2D>
 inline void launch_wbar_bwd(void *grad_u, void *part_s1, void *part_s2, const void *gw, const void *s1,
-                            const void *u, const void *s2, int64_t rows, int64_t S, int64_t R, hipStream_t st)
+                            const void *u, const void *s2, int64_t rows, int64_t S, int64_t R, bool mean, hipStream_t st)
 {
     constexpr int K = pick_k<T, LOG2D>();
     constexpr int VEC = Elem<T>::VEC;
@@ -138,23 +145,25 @@ inline void launch_wbar_bwd(void *grad_u, void *part_s1, void *part_s2, const vo
     const int64_t n_tiles = (n_chunks + 64 * K - 1) / (64 * K);
     const FastDiv dr = make_fastdiv((uint32_t)R), ds = make_fastdiv((uint32_t)S);
     const unsigned grid = (unsigned)((n_tiles + 3) / 4);
-#define WHVI_BWD(NT)                                                                                       \
-    hipLaunchKernelGGL((wbar_bwd_kernel<T, LOG2D, K, NT>), dim3(grid), dim3(256), 0, st, (T *)grad_u,      \
+#define WHVI_BWD(NT, MEAN)                                                                                       \
+    hipLaunchKernelGGL((wbar_bwd_kernel<T, LOG2D, K, NT, MEAN>), dim3(grid), dim3(256), 0, st, (T *)grad_u,      \
                        (T *)part_s1, (T *)part_s2, (const u32x4 *)gw, (const T *)s1, (const T *)u,         \
                        (const T *)s2, n_chunks, n_tiles, (uint32_t)rows, dr, ds)
-    if (n_chunks * 16 >= NT_MIN_BYTES) WHVI_BWD(true);
-    else WHVI_BWD(false);
+    const bool nt = n_chunks * 16 >= NT_MIN_BYTES;
+    if (mean) { if (nt) WHVI_BWD(true, true); else WHVI_BWD(false, true); }
+    else { if (nt) WHVI_BWD(true, false); else WHVI_BWD(false, false); }
 #undef WHVI_BWD
 }
 
 template <typename T>
 inline int wbar_bwd_dispatch(void *grad_u, void *part_s1, void *part_s2, const void *gw, const void *s1,
                              const void *u, const void *s2, int64_t J, int64_t S, int64_t R, int32_t log2d,
-                             void *stream)
+                             int32_t flags, void *stream)
 {
     constexpr int LV = ilog2(Elem<T>::VEC);
     g_err[0] = 0;
     if (J < 0 || S < 0 || R < 0) return fail(WHVI_ERR_ARG, "whvi_wbar_bwd: negative size%s", "");
+    if (flags & ~WHVI_WBAR_MEAN) return fail(WHVI_ERR_ARG, "whvi_wbar_bwd: unknown flags%s 0x%llx", "", flags);
     if (log2d < LV || log2d > max_single_pass_log2d<T>())
         return fail(WHVI_ERR_SIZE, "whvi_wbar_bwd: log2(D)%s = %lld is outside the supported range [%lld, ...]", "",
                     log2d, LV);
@@ -169,7 +178,7 @@ inline int wbar_bwd_dispatch(void *grad_u, void *part_s1, void *part_s2, const v
 #define WHVI_CASE(L)                                                                                       \
     case L:                                                                                                \
         if constexpr (L >= LV && L <= max_single_pass_log2d<T>())                                          \
-            launch_wbar_bwd<T, L>(grad_u, part_s1, part_s2, gw, s1, u, s2, rows, S, R, st);                 \
+            launch_wbar_bwd<T, L>(grad_u, part_s1, part_s2, gw, s1, u, s2, rows, S, R, (flags & WHVI_WBAR_MEAN) != 0, st);                 \
         break;
     switch (log2d) {
         WHVI_CASE(1) WHVI_CASE(2) WHVI_CASE(3) WHVI_CASE(4) WHVI_CASE(5) WHVI_CASE(6) WHVI_CASE(7)

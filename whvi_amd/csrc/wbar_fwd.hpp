@@ -1,0 +1,141 @@
+#pragma once
+// whvi_amd/csrc/wbar_fwd.hpp -- the as-written weight construction of src/weights.py:73,
+//     W[j,k] = S1_j . fwht( diag(u[j,k]) . fwht( diag(s2_j) ) )  (+ base[j]),
+// as its own kernel: zero HBM reads for the construction, one streaming write, and -- with `base` -- the
+// `w_bar(g_mu) + w_bar(g_sigma * eps_k)` sum of src/weights.py:93 folded into the epilogue (the mean matrix
+// is built once by a first launch and re-read from L2 / Infinity Cache by every sample).
+//
+// Same bits as the generic fused kernel with the identity input (fused_shs_kernel<EYE>): row i of diag(s2) is
+// one-hot, the butterflies of a one-hot row are exact, so fwht(diag(s2))[i,:] = s2_i * H[i,:] is generated
+// from the parity of popcount(i & d) instead of being transformed; u_i * (+/- s2_i) = +/- (u_i * s2_i) rounds
+// identically.  One transform per row instead of two.
+#include "kernels.hpp"
+
+namespace whvi {
+
+// rows are (J, S, R) x D; s1 / s2 are (J, D), u is (J, S, D); base is (J, R, D) or null
+template <typename T, int LOG2D, int K, bool NT>
+__global__ void __launch_bounds__(256)
+wbar_fwd_kernel(u32x4 *dst, const T *s1, const T *u, const T *s2, const u32x4 *base, int64_t n_chunks,
+                int64_t n_tiles, uint32_t n_rows, FastDiv by_r, FastDiv by_s)
+{
+    using E = Elem<T>;
+    using A = typename E::acc;
+    static_assert(sizeof(A) == sizeof(T), "f32 / f64 only");
+    constexpr int VEC = E::VEC;
+    constexpr int LV = ilog2(VEC);
+    constexpr int TILE = 64 * K;
+    constexpr int SH = LOG2D - LV;
+    constexpr uint32_t CPR = 1u << SH;
+    constexpr uint32_t D = 1u << LOG2D;
+    static_assert(LOG2D >= LV, "rows of at least one chunk");
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int64_t blk = blockIdx.x;
+    if (NT && (gridDim.x & 7) == 0) blk = (blk & 7) * (int64_t)(gridDim.x >> 3) + (blk >> 3);   // XCD-contiguous
+    const int64_t t = blk * 4 + wave;
+    if (t >= n_tiles) {
+        if constexpr (NT) __syncthreads();
+        return;
+    }
+    const int64_t tile0 = t * TILE;
+    const bool full = tile0 + TILE <= n_chunks;
+    const uint32_t row0 = (uint32_t)(tile0 >> SH);
+    auto chunk_row = [&](int k) -> uint32_t {
+        if constexpr (SH >= 6) return row0 + (uint32_t)((k * 64) >> SH);
+        else return row0 + (uint32_t)((k * 64 + lane) >> SH);
+    };
+    auto chunk_col = [&](int k) -> uint32_t { return (uint32_t)(k * 64 + lane) & (CPR - 1); };
+
+    A r[K][VEC];
+    A s1v[K];
+    uint32_t base_row[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const uint32_t row = chunk_row(k) < n_rows ? chunk_row(k) : 0u;   // rows past the end: valid operands, never stored
+        const uint32_t jk = by_r.div(row);
+        const uint32_t i = row - jk * by_r.d;
+        const uint32_t j = by_s.div(jk);
+        const A v = (A)u[(size_t)jk * D + i] * (A)s2[(size_t)j * D + i];
+        s1v[k] = (A)s1[(size_t)j * D + i];
+        base_row[k] = j * by_r.d + i;
+        const uint32_t d0 = chunk_col(k) * VEC;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) r[k][e] = (__builtin_popcount(i & (d0 + e)) & 1) ? -v : v;
+    }
+    fwht_tile<A, VEC, K, LOG2D, POLICY_DPP>(r, lane);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) r[k][e] = s1v[k] * r[k][e];
+        if (base != nullptr) {
+            A m[VEC];
+            E::unpack(base[(size_t)base_row[k] * CPR + chunk_col(k)], m);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) r[k][e] = m[e] + r[k][e];
+        }
+    }
+    if constexpr (NT) __syncthreads();
+    if (NT && full) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) tile_store_stream(dst + tile0, lane, k, E::pack(r[k]), TILE * 16);
+    } else {
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            if (full || tile0 + k * 64 + lane < n_chunks) st16<false>(dst + tile0 + k * 64 + lane, E::pack(r[k]));
+    }
+}
+
+template <typename T, int LOG2D>
+inline void launch_wbar_fwd(void *dst, const void *s1, const void *u, const void *s2, const void *base, int64_t rows,
+                            int64_t S, int64_t R, hipStream_t st)
+{
+    constexpr int K = pick_k<T, LOG2D>();
+    constexpr int VEC = Elem<T>::VEC;
+    const int64_t n_chunks = (rows << LOG2D) / VEC;
+    const int64_t n_tiles = (n_chunks + 64 * K - 1) / (64 * K);
+    const FastDiv dr = make_fastdiv((uint32_t)R), ds = make_fastdiv((uint32_t)S);
+    const unsigned grid = (unsigned)((n_tiles + 3) / 4);
+#define WHVI_FWD(NT)                                                                                        \
+    hipLaunchKernelGGL((wbar_fwd_kernel<T, LOG2D, K, NT>), dim3(grid), dim3(256), 0, st, (u32x4 *)dst,       \
+                       (const T *)s1, (const T *)u, (const T *)s2, (const u32x4 *)base, n_chunks, n_tiles,  \
+                       (uint32_t)rows, dr, ds)
+    if (n_chunks * 16 >= NT_MIN_BYTES) WHVI_FWD(true);
+    else WHVI_FWD(false);
+#undef WHVI_FWD
+}
+
+template <typename T>
+inline int wbar_fwd_dispatch(void *dst, const void *s1, const void *u, const void *s2, const void *base, int64_t J,
+                             int64_t S, int64_t R, int32_t log2d, void *stream)
+{
+    constexpr int LV = ilog2(Elem<T>::VEC);
+    g_err[0] = 0;
+    if (J < 0 || S < 0 || R < 0) return fail(WHVI_ERR_ARG, "whvi_wbar_fwd: negative size%s", "");
+    if (log2d < LV || log2d > max_single_pass_log2d<T>())
+        return fail(WHVI_ERR_SIZE, "whvi_wbar_fwd: log2(D)%s = %lld is outside the supported range [%lld, ...]", "",
+                    log2d, LV);
+    if (R > ((int64_t)1 << log2d)) return fail(WHVI_ERR_ARG, "whvi_wbar_fwd: R%s = %lld exceeds D", "", R);
+    const int64_t rows = J * S * R;
+    if (rows == 0) return WHVI_OK;
+    if (rows >= ((int64_t)1 << 32)) return fail(WHVI_ERR_SIZE, "whvi_wbar_fwd: rows are indexed with 32 bits%s", "");
+    if (!dst || !s1 || !u || !s2) return fail(WHVI_ERR_ARG, "whvi_wbar_fwd: null pointer%s", "");
+    if (((uintptr_t)dst & 15) || ((uintptr_t)base & 15))
+        return fail(WHVI_ERR_ALIGN, "whvi_wbar_fwd: %s pointer is not 16-byte aligned", ((uintptr_t)dst & 15) ? "dst" : "base");
+    hipStream_t st = (hipStream_t)stream;
+#define WHVI_CASE(L)                                                                                       \
+    case L:                                                                                                \
+        if constexpr (L >= LV && L <= max_single_pass_log2d<T>())                                          \
+            launch_wbar_fwd<T, L>(dst, s1, u, s2, base, rows, S, R, st);                                    \
+        break;
+    switch (log2d) {
+        WHVI_CASE(1) WHVI_CASE(2) WHVI_CASE(3) WHVI_CASE(4) WHVI_CASE(5) WHVI_CASE(6) WHVI_CASE(7)
+        WHVI_CASE(8) WHVI_CASE(9) WHVI_CASE(10) WHVI_CASE(11) WHVI_CASE(12) WHVI_CASE(13)
+    default: break;
+    }
+#undef WHVI_CASE
+    return after_launch("wbar_fwd");
+}
+
+}  // namespace whvi

@@ -1,0 +1,10 @@
+// whvi_amd/csrc/wbar_fwd_f64.hip -- weight construction (+ mean matrix add), double.  ABI: include/whvi_hip.h.
+#include "dispatch.hpp"
+#include "wbar_fwd.hpp"
+
+extern "C" __attribute__((visibility("default")))
+int whvi_wbar_fwd_f64(void *dst, const void *s1, const void *u, const void *s2, const void *base, int64_t J, int64_t S,
+                      int64_t R, int32_t log2d, void *stream)
+{
+    return whvi::wbar_fwd_dispatch<double>(dst, s1, u, s2, base, J, S, R, log2d, stream);
+}

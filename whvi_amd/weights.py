@@ -37,47 +37,63 @@ class WBarFunction(torch.autograd.Function):
 
         W[j, k] = diag(s1[j]) . fwht(diag(u[j, k]) . fwht(diag(s2[j])))[:rows]
 
-    as ONE fused HIP launch producing ``(J, S, rows, D)``.  ``s1, s2``: (J, D); ``u``: (J, S, D).
+    as ONE HIP launch producing ``(J, S, rows, D)``.  ``s1, s2``: (J, D); ``u``: (J, S, D).
     ``rows < D`` keeps only the first rows of every matrix (all that WHVIColumnMatrix uses,
     src/weights.py:245); row i depends on ``s1[j,i], u[j,k,i], s2[j,i]`` alone.
+    ``mean_plus``: ``u`` is ``(J, 1 + S, D)`` and the result is ``W[j, 0] + W[j, 1 + k]`` for k < S -- the
+    ``w_bar(g_mu) + w_bar(g_sigma * eps_k)`` of src/weights.py:93 -- built as two launches (the mean matrix once,
+    then every sample's matrix with the mean added in the epilogue) instead of 1 + S matrices and an add pass.
 
-    Forward: ``whvi_fused_shs_ex`` with the identity input synthesised in-kernel (no HBM read),
-    row-axis scales c = s2, b = u, a = s1 -- multiply / butterfly order and roundings exactly those
-    of src/weights.py:73.  Backward: the adjoint chain (H is symmetric, so every FWHT's adjoint is
+    Forward: ``whvi_wbar_fwd`` (no HBM read; multiply / butterfly order and roundings exactly those of
+    src/weights.py:73, bit-identical to ``whvi_fused_shs_ex`` with the identity input).  Backward: the adjoint chain (H is symmetric, so every FWHT's adjoint is
     the same FWHT, src/fwht/cuda/fwht.py:14-16): one fused launch (``whvi_wbar_bwd``) for first-order
     gradients, the chain written with differentiable ops when a graph of the backward is requested."""
 
     @staticmethod
-    def forward(ctx, s1, u, s2, rows):
+    def forward(ctx, s1, u, s2, rows, mean_plus=False):
         from whvi_amd import _hip
-        J, S, D = u.shape
+        J, U, D = u.shape
         R = D if rows is None else int(rows)
         ctx.save_for_backward(s1, u, s2)
-        ctx.rows = R
-        # rows of each (j, k) matrix form one group of R rows; with several matrices every group carries its
-        # own s1 / s2 (per-sample outer scales), a single matrix shares them
+        ctx.rows, ctx.mean_plus = R, bool(mean_plus)
+        if _hip.wbar_bwd_supported(u.dtype, D):
+            # dedicated launch (whvi_wbar_fwd): one transform per row, no HBM read
+            if not mean_plus:
+                return _hip.wbar_fwd(s1, u, s2, R)
+            mean = _hip.wbar_fwd(s1, u[:, :1], s2, R)                         # (J, 1, R, D): w_bar(g_mu), once
+            return _hip.wbar_fwd(s1, u[:, 1:], s2, R, base=mean.view(J, R, D))  # + w_bar(g_sigma * eps_k), per sample
+        # rows shorter than one 16-byte chunk (D = 1, 2): the generic fused launch with the identity input.  Rows
+        # of each (j, k) matrix form one group of R rows; with several matrices every group carries its own s1 / s2
         if J == 1:
-            out = _hip.fused_shs(None, a=s1[0, :R], b=u[0, :, :R], c=s2[0, :R], axis="row", n_samples=S,
-                                 sample_stride=R, group_rows=R, rows=S * R, d=D, dtype=u.dtype, device=u.device)
+            out = _hip.fused_shs(None, a=s1[0, :R], b=u[0, :, :R], c=s2[0, :R], axis="row", n_samples=U,
+                                 sample_stride=R, group_rows=R, rows=U * R, d=D, dtype=u.dtype, device=u.device)
         else:
-            out = _hip.fused_shs(None, a=s1[:, :R].repeat_interleave(S, dim=0), b=u[:, :, :R],
-                                 c=s2[:, :R].repeat_interleave(S, dim=0), axis="row", n_samples=J * S,
-                                 sample_stride=R, group_rows=R, rows=J * S * R, d=D, dtype=u.dtype,
+            out = _hip.fused_shs(None, a=s1[:, :R].repeat_interleave(U, dim=0), b=u[:, :, :R],
+                                 c=s2[:, :R].repeat_interleave(U, dim=0), axis="row", n_samples=J * U,
+                                 sample_stride=R, group_rows=R, rows=J * U * R, d=D, dtype=u.dtype,
                                  device=u.device, a_per_sample=True, c_per_sample=True)
-        return out.view(J, S, R, D)
+        out = out.view(J, U, R, D)
+        return out[:, :1] + out[:, 1:] if mean_plus else out
 
     @staticmethod
     def backward(ctx, grad_W):
         s1, u, s2 = ctx.saved_tensors
-        J, S, D = u.shape
+        J, U, D = u.shape
         R = ctx.rows
         from whvi_amd import _hip
         if not torch.is_grad_enabled() and _hip.wbar_bwd_supported(u.dtype, D):
             # first-order backward (the training loop): one launch, grad_W read once (whvi_wbar_bwd)
-            out = _hip.wbar_bwd(grad_W, s1, u, s2)                      # (3, J, S, D): grad_u, per-sample s1 / s2 parts
-            parts = out[1:, :, 0] if S == 1 else out[1:].sum(dim=2)    # one reduction for both scale vectors
-            return parts[0], out[0], parts[1], None
+            out = _hip.wbar_bwd(grad_W, s1, u, s2, mean=ctx.mean_plus)   # (3, J, U, D): grad_u, per-sample s1 / s2 parts
+            if ctx.mean_plus:
+                # slot 0 <- sum of the sample slots: dL/du_mean and the per-matrix totals of s1 / s2, one reduction
+                torch.sum(out[:, :, 1:], dim=2, out=out[:, :, 0])
+                return out[1, :, 0], out[0], out[2, :, 0], None, None
+            parts = out[1:, :, 0] if U == 1 else out[1:].sum(dim=2)     # one reduction for both scale vectors
+            return parts[0], out[0], parts[1], None, None
         # create_graph=True (or a shape outside the fused kernel): the same chain as differentiable ops
+        if ctx.mean_plus:                        # W[j,k] = w_bar(u_0) + w_bar(u_{1+k}): the mean takes the summed gradient
+            grad_W = torch.cat((grad_W.sum(dim=1, keepdim=True), grad_W), dim=1)
+        S = U
         fw = fwht_cuda.apply
         with torch.enable_grad():
             s1r, s2r, ur = s1[:, :R], s2[:, :R], u[:, :, :R]
@@ -95,7 +111,7 @@ class WBarFunction(torch.autograd.Function):
             else:
                 pad = (0, D - R)
                 grad_s1, grad_u, grad_s2 = (F.pad(grad_s1_r, pad), F.pad(grad_u_r, pad), F.pad(grad_s2_r, pad))
-        return grad_s1, grad_u, grad_s2, None
+        return grad_s1, grad_u, grad_s2, None, None
 
 
 class ReparamKLFunction(torch.autograd.Function):
@@ -196,10 +212,11 @@ class WHVISquarePow2Matrix(nn.Module):
         return kl_diag_normal(self.g_mu, self.g_sigma, torch.zeros(self.D, device=dev),
                               torch.ones(self.D, device=dev) * self.lambda_)
 
-    def _w_bar_stack(self, u, rows=None):
+    def _w_bar_stack(self, u, rows=None, mean_plus=False):
         """``w_bar`` for every row of ``u`` (S, D) -> (S, D, D) (first ``rows`` rows on the GPU)."""
         if u.device.type == "cuda":
-            return WBarFunction.apply(self.s1.unsqueeze(0), u.unsqueeze(0), self.s2.unsqueeze(0), rows).squeeze(0)
+            return WBarFunction.apply(self.s1.unsqueeze(0), u.unsqueeze(0), self.s2.unsqueeze(0), rows,
+                                      mean_plus).squeeze(0)
         base = self.fwht(torch.diag(self.s2))
         return torch.stack([matmul_diag_left(self.s1, self.fwht(matmul_diag_left(row, base)))
                             for row in u])
@@ -231,8 +248,8 @@ class WHVISquarePow2Matrix(nn.Module):
         if self.exploit_diagonal:
             return h * (self._w_bar_diagonal(self.g_mu) + self._w_bar_diagonal(self.g_sigma * epsilon))
         if self.g_mu.device.type == "cuda":
-            pair = self._w_bar_stack(torch.stack((self.g_mu, self.g_sigma * epsilon)))
-            return h @ _mean_plus_rest(pair, 0).squeeze(0).T
+            W = self._w_bar_stack(torch.stack((self.g_mu, self.g_sigma * epsilon)), mean_plus=True)   # (1, D, D)
+            return h @ W.squeeze(0).T
         return h @ (self.w_bar(self.g_mu) + self.w_bar(self.g_sigma * epsilon)).T
 
     def forward(self, x, use_lrt=True):
@@ -257,10 +274,10 @@ class WHVISquarePow2Matrix(nn.Module):
         u = u.squeeze(0)                                                          # (1 + S, D)
         self._mc_kl = None if kl is None else kl.squeeze(0)   # KL of this pass, for WHVINetwork.loss
         if u.device.type == "cuda":
-            W = self._w_bar_stack(u)
+            W = self._w_bar_stack(u, mean_plus=True)                             # (S, D, D), the sum in-kernel
         else:
             W = torch.stack([self.w_bar(row) for row in u])
-        W = _mean_plus_rest(W, 0)                                                # (S, D, D)
+            W = _mean_plus_rest(W, 0)                                            # (S, D, D)
         out = torch.matmul(x, W.transpose(1, 2))                                 # broadcasts a 2-D x
         return out + self.bias if self.bias is not None else out
 
@@ -298,7 +315,7 @@ class WHVIStackedMatrix(nn.Module):
     def kl(self):
         return sum(weight.kl for weight in self.weight_matrices)
 
-    def _stacked_w_bar(self, parts):
+    def _stacked_w_bar(self, parts, mean_plus=False):
         """All sub-matrices in ONE fused launch (the reference loops over them,
         src/weights.py:177-180: 4 FWHT launches each).  ``parts(m, eps)`` returns the list of ``u``
         vectors of sub-matrix m; result (stack, len(parts), D, D)."""
@@ -310,7 +327,7 @@ class WHVIStackedMatrix(nn.Module):
         g_mu = torch.stack([m.g_mu for m in self.weight_matrices])
         g_sigma = F.softplus(torch.stack([m.g_rho for m in self.weight_matrices]))
         u = torch.stack(parts(g_mu, g_sigma, eps), dim=1)          # (stack, n_parts, D)
-        return WBarFunction.apply(s1, u, s2, None)
+        return WBarFunction.apply(s1, u, s2, None, mean_plus)
 
     def _on_gpu(self):
         return self.weight_matrices[0].g_mu.device.type == "cuda"
@@ -323,8 +340,8 @@ class WHVIStackedMatrix(nn.Module):
 
     def sample_lrt(self, h):
         if self._on_gpu():
-            W = self._stacked_w_bar(lambda mu, sg, eps: [mu, sg * eps])
-            W = _mean_plus_rest(W, 1).reshape(self.stack * self.D_in, self.D_in)  # cat over sub-matrices
+            W = self._stacked_w_bar(lambda mu, sg, eps: [mu, sg * eps], mean_plus=True)   # (stack, 1, D, D)
+            W = W.reshape(self.stack * self.D_in, self.D_in)                      # cat over sub-matrices
             return h @ W.T
         return torch.cat([weight.sample_lrt(h) for weight in self.weight_matrices], dim=1)
 
@@ -342,10 +359,11 @@ class WHVIStackedMatrix(nn.Module):
         u, kl = _reparam(g_mu, g_rho, eps, self.lambda_)                            # (J, 1 + S, D)
         self._mc_kl = None if kl is None else kl.sum()
         if dev.type == "cuda":
-            W = WBarFunction.apply(s1, u, s2, None)
+            W = WBarFunction.apply(s1, u, s2, None, True)                           # (J, S, D, D), the sum in-kernel
         else:
             W = torch.stack([torch.stack([m.w_bar(row) for row in u[j]]) for j, m in enumerate(self.weight_matrices)])
-        W = _mean_plus_rest(W, 1).transpose(0, 1).reshape(S, J * D, D)              # (S, stack*D, D)
+            W = _mean_plus_rest(W, 1)
+        W = W.transpose(0, 1).reshape(S, J * D, D)                                  # (S, stack*D, D)
         x_padded = torch.zeros((*x.size()[:-1], D), device=x.device)
         x_padded[..., :self.n_in] = x
         out = torch.matmul(x_padded, W.transpose(1, 2))
