@@ -82,6 +82,14 @@ inline int check_common(const void *dst, const void *src, int64_t rows, int32_t 
 // non-temporal loads/stores for streams far larger than the 256 MiB Infinity Cache.  Small problems
 // use 256-thread blocks (more CUs busy) and cached accesses (the consumer is usually next in line).
 constexpr int64_t NT_MIN_BYTES = (int64_t)256 << 20;
+// Streaming (non-temporal) launch iff the launch's working set -- the buffer once when in place, source plus
+// destination otherwise -- EXCEEDS the 256 MiB Infinity Cache.  Measured crossover (tools/probe_nt_threshold.py,
+// D = 4096 f32): in place, cached accesses win up to 256 MiB (6.7 vs 5.7 TB/s) and lose from 320 MiB (5.7 vs 5.8);
+// out of place they win up to 128 MiB per buffer (7.3 vs 5.4) and lose from 192 MiB (5.2 vs 5.7).
+inline bool stream_sized(int64_t bytes, const void *dst, const void *src)
+{
+    return (dst == src || src == nullptr ? bytes : 2 * bytes) > NT_MIN_BYTES;
+}
 
 // variant word of whvi_fwht_ex: documented in include/whvi_hip.h (0 = production launch).
 // FULL = the extra tuning variants are compiled (f32, D = 512..4096).
@@ -104,7 +112,7 @@ inline void launch_rows(void *dst, const void *src, int64_t n_chunks, int varian
     } while (0)
     if (variant == 0) {   // production path
         const bool big = n_tiles >= (int64_t)32 * num_cu();
-        const bool nt = n_chunks * 16 >= NT_MIN_BYTES;
+        const bool nt = stream_sized(n_chunks * 16, dst, src);
         constexpr int BIG = big_block<T, LOG2D>();
         if constexpr (BIG > 256) {
             if (big && nt) {
@@ -270,7 +278,7 @@ inline void launch_fused(void *dst, const void *src, const void *a, const void *
     const FastDiv ds = make_fastdiv((uint32_t)sample_stride), dn = make_fastdiv((uint32_t)n_samples),
                   dg = make_fastdiv((uint32_t)group_rows);
     const bool big = SMALL_TILE && n_tiles >= (int64_t)32 * num_cu();
-    const bool nt = big && n_chunks * 16 >= NT_MIN_BYTES;
+    const bool nt = big && stream_sized(n_chunks * 16, dst, src);
 #define WHVI_FUSED(AX, EYE, NT, BLK, POL, STG)                                                          \
     hipLaunchKernelGGL((fused_shs_kernel<T, LOG2D, K, AX, EYE, NT, BLK, POL, STG>),                     \
                        dim3((unsigned)((n_tiles + (BLK / 64) - 1) / (BLK / 64))), dim3(BLK),            \
