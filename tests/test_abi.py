@@ -52,6 +52,32 @@ def test_argument_checks_without_gpu():
     assert [L.whvi_max_log2d(i) for i in range(5)] == [24, 24, 13, 24, 13] and L.whvi_max_log2d(7) == -1
 
 
+def test_argument_checks_of_the_training_step_entry_points():
+    """whvi_wbar_fwd / _bwd, whvi_reparam_kl_bwd, whvi_gauss_mnll: bad arguments are reported before any launch."""
+    from whvi_amd import _hip
+    L = _hip.lib()
+    buf = (ctypes.c_char * 512)()
+    p16 = (ctypes.addressof(buf) + 15) & ~15
+    i64x3 = ctypes.c_int64 * 3
+    assert L.whvi_wbar_fwd_f32(p16, p16, p16, p16, None, 1, 1, 4, 1, None) == -2 and "supported range" in _hip.last_error()
+    assert L.whvi_wbar_fwd_f32(p16, p16, p16, p16, None, 1, 1, 9, 3, None) == -1 and "exceeds D" in _hip.last_error()
+    assert L.whvi_wbar_fwd_f64(None, p16, p16, p16, None, 1, 1, 2, 1, None) == -1 and "null" in _hip.last_error()
+    assert L.whvi_wbar_fwd_f32(p16 + 4, p16, p16, p16, None, 1, 1, 4, 2, None) == -3
+    assert L.whvi_wbar_fwd_f32(None, None, None, None, None, 0, 3, 4, 2, None) == 0            # no matrices
+    assert L.whvi_wbar_bwd_f32(p16, p16, p16, p16, p16, p16, p16, 1, 1, 4, 14, 0, None) == -2
+    assert L.whvi_wbar_bwd_f32(p16, p16, p16, p16, p16, p16, p16, 1, 1, 4, 2, 8, None) == -1 and "flags" in _hip.last_error()
+    assert L.whvi_wbar_bwd_f64(p16, p16, p16, None, p16, p16, p16, 1, 1, 2, 1, 0, None) == -1
+    assert L.whvi_wbar_bwd_f32(None, None, None, None, None, None, None, 2, 0, 4, 2, 1, None) == 0
+    assert L.whvi_reparam_kl_bwd_f32(p16, p16, None, None, p16, p16, p16, p16, 1, 1, 4, 0.0, None) == -1   # lambda <= 0
+    assert L.whvi_reparam_kl_bwd_f32(None, p16, None, None, p16, p16, p16, p16, 1, 1, 4, 1.0, None) == -1
+    assert L.whvi_reparam_kl_bwd_f32(None, None, None, None, None, None, None, None, 0, 1, 4, 1.0, None) == 0
+    assert L.whvi_gauss_mnll_f32(p16, p16, p16, p16, None, None, None, 1.0, None) == -1
+    assert L.whvi_gauss_mnll_f32(p16, p16, p16, p16, i64x3(2, -1, 1), i64x3(1, 1, 1), i64x3(1, 1, 0), 1.0, None) == -1
+    assert L.whvi_gauss_mnll_bwd_f32(None, None, p16, p16, p16, p16, p16, i64x3(1, 1, 1), i64x3(1, 1, 1), i64x3(1, 1, 0),
+                                     1.0, None) == -1
+    assert L.whvi_gauss_mnll_blocks(1) == 1 and L.whvi_gauss_mnll_blocks(10 ** 9) == 2048
+
+
 def test_gpu_tensors_never_fall_back(monkeypatch):
     """A missing native library is an error, not a CPU detour."""
     from whvi_amd import _hip
