@@ -102,3 +102,57 @@ def test_random_fused(case, log2d, S, axis, layout, B, hip_lib):
     t = lambda v: torch.from_numpy(v).to(DEV)   # noqa: E731
     got = _hip.fused_shs(t(x), t(a), t(b), t(c), **kw).cpu().numpy()
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (case, log2d, S, axis, layout, rows)
+
+
+def _wbar_cases():
+    rng = np.random.default_rng(4242)
+    out = []
+    for i in range(max(16, N_CASES // 2)):
+        dt = torch.float64 if i % 4 == 3 else torch.float32
+        log2d = int(rng.integers(1 if dt == torch.float64 else 2, 12))
+        d = 1 << log2d
+        J = int(rng.integers(1, 5))
+        S = int(rng.integers(1, 5))
+        R = d if rng.random() < 0.5 else int(rng.integers(1, d + 1))
+        if J * S * R * d > (1 << 24):
+            J, S = 1, 1
+        out.append((i, dt, J, S, d, R, bool(i % 2)))
+    return out
+
+
+@pytest.mark.parametrize("case,dtype,J,S,D,R,mean", _wbar_cases())
+def test_random_weight_construction(case, dtype, J, S, D, R, mean, hip_lib):
+    """whvi_wbar_fwd / whvi_wbar_bwd on random (J, S, D, R): the forward bit for bit against the CPU oracle's
+    two-transform pipeline on every matrix (and the in-epilogue mean add against a separate add), the backward
+    against the float64 closed form the as-written matrix implies (W = D diag(s1 u s2))."""
+    g = torch.Generator().manual_seed(1000 + case)
+    npdt = np.float32 if dtype == torch.float32 else np.float64
+    U = S + 1 if mean else S
+    s1, s2 = (torch.randn(J, D, generator=g, dtype=dtype) for _ in range(2))
+    u = torch.randn(J, U, D, generator=g, dtype=dtype)
+    every = _hip.wbar_fwd(s1.to(DEV), u.to(DEV), s2.to(DEV), R).cpu().numpy()          # (J, U, R, D)
+    eye = np.eye(D, dtype=npdt)[:R]
+    for j in range(J):
+        want = oracle.pipeline(np.tile(eye, (U, 1)), s1[j, :R].numpy(), u[j, :, :R].numpy(), s2[j, :R].numpy(),
+                               n_samples=U, sample_stride=R, group_rows=R, axis="row").reshape(U, R, D)
+        assert np.array_equal(every[j].view(np.uint8), want.view(np.uint8)), (case, j)
+    from whvi_amd.weights import WBarFunction
+    p = [t.to(DEV).requires_grad_() for t in (s1, u, s2)]
+    W = WBarFunction.apply(p[0], p[1], p[2], None if R == D else R, mean)
+    if mean:
+        assert np.array_equal(W.detach().cpu().numpy().view(np.uint8), (every[:, :1] + every[:, 1:]).view(np.uint8))
+    gw = torch.randn(W.shape, generator=g, dtype=dtype)
+    got = torch.autograd.grad(W, p, gw.to(DEV))
+    # closed form in float64: W[j,k] = D diag(s1 (u_k [+ u_0]) s2)
+    s1d, s2d, ud, gd = s1.double()[:, None, :R], s2.double()[:, None, :R], u.double()[:, :, :R], gw.double()
+    diag = torch.diagonal(gd, dim1=2, dim2=3)                                                 # (J, S, R)
+    g_u_samples = D * s1d * s2d * diag
+    usum = ud[:, 1:] + ud[:, :1] if mean else ud
+    want_u = torch.cat((g_u_samples.sum(1, keepdim=True), g_u_samples), dim=1) if mean else g_u_samples
+    want = {"s1": (D * usum * s2d * diag).sum(1), "u": want_u, "s2": (D * s1d * usum * diag).sum(1)}
+    noise = (2e-6 if dtype == torch.float32 else 1e-14) * D * float(gd.abs().max()) * 8 * U
+    bound = noise * float(max(s1d.abs().max(), 1) * max(s2d.abs().max(), 1) * max(ud.abs().max(), 1))
+    for name, a in zip(("s1", "u", "s2"), got):
+        a = a.double().cpu()
+        assert float((a[..., :R] - want[name]).abs().max()) <= bound, (case, name)
+        assert R == D or float(a[..., R:].abs().max()) == 0.0
