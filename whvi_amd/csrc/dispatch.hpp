@@ -133,7 +133,9 @@ inline void launch_rows(void *dst, const void *src, int64_t n_chunks, int varian
                 else
                     hipLaunchKernelGGL((fwht_rows_kernel<T, LOG2D, K, POLICY_DPP, false, true, 256, 1>),
                                        dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, st, d, s, n_chunks, n_tiles);
-            } else if (big) WHVI_LAUNCH(POLICY_DPP, false, false, BIG);
+            } else if (big && sizeof(T) == 8) WHVI_LAUNCH(POLICY_DPP, false, false, BIG);
+            // cache-resident sizes: 256-thread blocks match or beat 1024 at every size (tools/probe_midsize.py:
+            // 6.6-6.8 vs 6.5-6.7 TB/s at 128-256 MiB in place, 6.7 vs 5.3 at 32 MiB)
             else WHVI_LAUNCH(POLICY_DPP, false, false, 256);
         } else {
             WHVI_LAUNCH(POLICY_DPP, false, false, 256);
