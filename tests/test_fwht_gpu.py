@@ -136,8 +136,8 @@ def test_involution_and_linearity_full_size(hip_lib):
 @pytest.mark.parametrize("dtype,log2d,rows", [(torch.float32, 10, 40000), (torch.float16, 12, 12000),
                                               (torch.float64, 11, 9000), (torch.int32, 9, 70001)])
 def test_production_launch_geometries(dtype, log2d, rows, hip_lib):
-    """Mid-size problems take the 1024-thread-block launch with cached accesses (>= 32 tiles per CU
-    but < 256 MiB), incl. a partial last tile / partial last block; spot-check rows against the
+    """Mid-size problems (>= 32 tiles per CU but inside the Infinity Cache) take cached accesses -- 256-thread
+    blocks, f64 1024 -- incl. a partial last tile / partial last block; spot-check rows against the
     oracle and the whole tensor through H.H = D.I on small integers."""
     d = 1 << log2d
     g = torch.Generator(device=DEV).manual_seed(5)
@@ -175,7 +175,8 @@ def test_streaming_launch_of_16bit_types(dtype, log2d, rows, hip_lib):
 
 def test_headline_size_in_place_involution(hip_lib):
     """The bench workload itself (D = 4096, 2^20 rows = 16 GiB, > 2^32 bytes of offsets, in place,
-    non-temporal 1024-thread launch): H.H = 4096.I exactly on small integers, plus oracle rows."""
+    streaming launch: non-temporal, 256-thread blocks + store barrier): H.H = 4096.I exactly on small integers, plus
+    oracle rows."""
     free, _ = torch.cuda.mem_get_info()
     if free < 40 * 2 ** 30:
         pytest.skip("needs ~34 GiB of free HBM")
