@@ -190,6 +190,17 @@ int whvi_wbar_bwd_f64(void *grad_u, void *part_s1, void *part_s2, const void *gr
                       const void *u, const void *s2, int64_t J, int64_t S, int64_t R, int32_t log2d,
                       int32_t flags, void *stream);
 
+/* whvi_reparam_kl_f32 with the eps draw inside the kernel: Philox4x32-10 + Box-Muller, one standard
+ * normal per (matrix, sample, element), written to eps_out (J, S, D) for the backward pass / inspection.  The
+ * generator state is three 64-bit words in DEVICE memory, state = {seed, launch offset, scratch (must be 0)}; the
+ * kernel advances the offset itself when its last block finishes, so nothing about the draw is baked into the
+ * launch: safe to capture in a hipGraph (every replay draws fresh eps).  One stream per state at a time.  The
+ * stream of numbers is this library's own (not torch.randn's); for bit-level parity work inject eps through
+ * whvi_reparam_kl_f32, which computes the same u / sigma / KL from a given eps. */
+int whvi_reparam_kl_philox_f32(void *u, void *sigma, void *kl_part, void *eps_out, const void *g_mu,
+                               const void *g_rho, void *state, int64_t J, int64_t S, int64_t D, float lambda_,
+                               void *stream);
+
 /* Backward of whvi_reparam_kl_f32 in one launch (closed form): grad_u (J, 1+S, D) and grad_kl (J) are the incoming
  * gradients (either may be NULL = zero), sigma the forward's saved output; writes grad_mu, grad_rho (J, D).
  * Replaces autograd over softplus / mul / kl_diag_normal (src/weights.py:43-64,82-83; src/utils.py:49-71). */

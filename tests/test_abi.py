@@ -71,6 +71,9 @@ def test_argument_checks_of_the_training_step_entry_points():
     assert L.whvi_reparam_kl_bwd_f32(p16, p16, None, None, p16, p16, p16, p16, 1, 1, 4, 0.0, None) == -1   # lambda <= 0
     assert L.whvi_reparam_kl_bwd_f32(None, p16, None, None, p16, p16, p16, p16, 1, 1, 4, 1.0, None) == -1
     assert L.whvi_reparam_kl_bwd_f32(None, None, None, None, None, None, None, None, 0, 1, 4, 1.0, None) == 0
+    assert L.whvi_reparam_kl_philox_f32(p16, p16, p16, p16, p16, p16, None, 1, 1, 4, 1.0, None) == -1   # no generator state
+    assert L.whvi_reparam_kl_philox_f32(p16, p16, p16, p16, p16, p16, p16 + 4, 1, 1, 4, 1.0, None) == -3
+    assert L.whvi_reparam_kl_philox_f32(None, None, None, None, None, None, None, 0, 1, 4, 1.0, None) == 0
     assert L.whvi_gauss_mnll_f32(p16, p16, p16, p16, None, None, None, 1.0, None) == -1
     assert L.whvi_gauss_mnll_f32(p16, p16, p16, p16, i64x3(2, -1, 1), i64x3(1, 1, 1), i64x3(1, 1, 0), 1.0, None) == -1
     assert L.whvi_gauss_mnll_bwd_f32(None, None, p16, p16, p16, p16, p16, i64x3(1, 1, 1), i64x3(1, 1, 1), i64x3(1, 1, 0),

@@ -562,3 +562,66 @@ def test_wbar_mean_plus_forward_and_backward(dtype, J, S, D, R, hip_lib):
         b = b.detach()
         assert a.shape == b.shape, name
         assert float((a - b).abs().max()) <= tol * (float(b.abs().max()) or 1.0) * math.sqrt(D) * (S + 1), name
+
+
+def test_inkernel_philox_reparameterisation(hip_lib):
+    """whvi_reparam_kl_philox_f32: the eps it reports reproduce u / sigma / KL bit for bit through the
+    injectable-eps kernel; the draw is standard normal (moments, tail mass, no duplicates across the index space),
+    repeatable from (seed, offset) and advanced by the kernel itself."""
+    J, S, D, lam = 3, 21, 1000, 0.7
+    g = torch.Generator().manual_seed(5)
+    mu = torch.randn(J, D, generator=g).to(DEV)
+    rho = (torch.rand(J, D, generator=g) * 3 - 3).to(DEV)
+    state = _hip.new_rng_state(torch.device(DEV), seed=1234)
+    u, sigma, kl, eps = _hip.reparam_kl_philox(mu, rho, S, lam, state)
+    assert state.tolist() == [1234, 2, 0]                                  # two Philox calls per thread, scratch reset
+    u2, sigma2, kl2 = _hip.reparam_kl(mu, rho, eps, lam)
+    assert torch.equal(u, u2) and torch.equal(sigma, sigma2) and torch.equal(kl, kl2)
+    # repeatable from the state, different after it advanced
+    again = _hip.reparam_kl_philox(mu, rho, S, lam, torch.tensor([1234, 0, 0], dtype=torch.int64, device=DEV))[3]
+    nxt = _hip.reparam_kl_philox(mu, rho, S, lam, state)[3]
+    assert torch.equal(again, eps) and not torch.equal(nxt, eps) and state.tolist() == [1234, 4, 0]
+    other_seed = _hip.reparam_kl_philox(mu, rho, S, lam, _hip.new_rng_state(torch.device(DEV), seed=1235))[3]
+    assert not torch.equal(other_seed, eps)
+    # distribution: a large draw
+    big = _hip.reparam_kl_philox(torch.zeros(8, 4096, device=DEV), torch.zeros(8, 4096, device=DEV), 64, 1.0,
+                                 _hip.new_rng_state(torch.device(DEV), seed=7))[3].double().flatten()
+    n = big.numel()                                                         # 2.1 M samples
+    assert torch.isfinite(big).all()
+    assert abs(float(big.mean())) < 4 / math.sqrt(n) and abs(float(big.var()) - 1.0) < 6 * math.sqrt(2 / n)
+    assert abs(float((big ** 3).mean())) < 0.02 and abs(float((big ** 4).mean()) - 3.0) < 0.05
+    for z, p in ((1.0, 0.682689), (2.0, 0.954500), (3.0, 0.997300)):
+        assert abs(float((big.abs() < z).double().mean()) - p) < 5 * math.sqrt(p * (1 - p) / n)
+    assert torch.unique(big).numel() > 0.95 * n                             # no repeated blocks of the counter space
+    grid = big.view(8, 64, 4096)
+    for a, b in ((grid[:, :, :-1], grid[:, :, 1:]), (grid[:, :-1], grid[:, 1:]), (grid[:-1], grid[1:])):
+        assert abs(float((a * b).mean())) < 5 / math.sqrt(a.numel())        # neighbours along every axis uncorrelated
+
+
+def test_inkernel_rng_in_the_network_and_under_hipgraph(hip_lib):
+    """Opt-in ``set_inkernel_rng``: a training step differentiates through the in-kernel draw (same one-launch
+    backward), predictions vary from call to call, and a captured predictive pass draws fresh eps on every replay."""
+    import torch.nn as nn
+    from whvi_amd.graphs import GraphedPredictor
+    from whvi_amd.networks import WHVIRegression
+    torch.manual_seed(0)
+    net = WHVIRegression([WHVILinear(1, 32), nn.Tanh(), WHVILinear(32, 32), nn.Tanh(), WHVILinear(32, 1)],
+                         train_samples=4, eval_samples=8).to(DEV).set_inkernel_rng(True)
+    x = torch.linspace(-1, 1, 50, device=DEV).unsqueeze(1)
+    y = torch.sin(3 * x)
+    net.train()
+    loss = net.loss(x, y, n=50)
+    loss.backward()
+    assert torch.isfinite(loss) and all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
+    assert any(float(p.grad.abs().max()) > 0 for n_, p in net.named_parameters() if n_.endswith("g_rho"))
+    net.eval()
+    with torch.no_grad():
+        a, b = net(x), net(x)
+    assert a.shape == (50, 1, 8) and not torch.equal(a, b)
+    gp = GraphedPredictor(net, x, 8)
+    r1 = gp(x).clone()
+    r2 = gp(x).clone()
+    assert not torch.equal(r1, r2) and torch.isfinite(r1).all() and torch.isfinite(r2).all()
+    # every layer's generator moved on
+    states = [m._rng_state for m in net.modules() if getattr(m, "_rng_state", None) is not None]
+    assert len(states) == 3 and all(int(s[1]) > 0 and int(s[2]) == 0 for s in states)

@@ -63,6 +63,8 @@ def _declare_f3(lib):
     lib.whvi_reparam_kl_blocks.argtypes = [i64]
     lib.whvi_reparam_kl_f32.restype = ctypes.c_int
     lib.whvi_reparam_kl_f32.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i64, ctypes.c_float, vp]
+    lib.whvi_reparam_kl_philox_f32.restype = ctypes.c_int
+    lib.whvi_reparam_kl_philox_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, ctypes.c_float, vp]
     lib.whvi_reparam_kl_bwd_f32.restype = ctypes.c_int
     lib.whvi_reparam_kl_bwd_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, ctypes.c_float, vp]
     p64 = ctypes.POINTER(ctypes.c_int64)
@@ -257,6 +259,39 @@ def reparam_kl(g_mu: torch.Tensor, g_rho: torch.Tensor, eps: torch.Tensor, lambd
                                    eps.data_ptr() if S > 0 else None, J, S, D, float(lambda_), _stream(g_mu))
     _check(rc, "whvi_reparam_kl")
     return u, sigma, (part.sum(dim=1) if nblk > 1 else part[:, 0])
+
+
+def new_rng_state(device, seed: int = None) -> torch.Tensor:
+    """Device-resident generator state for ``reparam_kl_philox``: int64 [seed, launch offset, scratch].  Without an
+    explicit seed one is drawn from torch's default CPU generator, so ``torch.manual_seed`` makes runs repeatable."""
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    return torch.tensor([int(seed), 0, 0], dtype=torch.int64, device=device)
+
+
+def reparam_kl_philox(g_mu: torch.Tensor, g_rho: torch.Tensor, n_samples: int, lambda_: float, state: torch.Tensor):
+    """One launch, eps drawn in the kernel: (u (J, 1+S, D), sigma (J, D), kl (J,), eps (J, S, D)); see
+    whvi_reparam_kl_philox_f32 in include/whvi_hip.h.  ``state`` comes from ``new_rng_state`` and is advanced in place."""
+    if g_mu.device.type != "cuda" or g_mu.dtype != torch.float32:
+        raise RuntimeError("reparam_kl_philox: float32 CUDA tensors only")
+    if state.dtype != torch.int64 or state.numel() < 3 or state.device != g_mu.device or not state.is_contiguous():
+        raise RuntimeError("reparam_kl_philox: state must be a contiguous int64 tensor of 3 words on the same device")
+    J, D = g_mu.shape
+    S = int(n_samples)
+    g_mu, g_rho = g_mu.contiguous(), g_rho.contiguous()
+    L = lib()
+    nblk = (D + 255) // 256
+    dev = g_mu.device
+    u = torch.empty((J, S + 1, D), dtype=torch.float32, device=dev)
+    sigma = torch.empty((J, D), dtype=torch.float32, device=dev)
+    part = torch.empty((J, nblk), dtype=torch.float32, device=dev)
+    eps = torch.empty((J, S, D), dtype=torch.float32, device=dev)
+    with _OnDevice(dev):
+        rc = L.whvi_reparam_kl_philox_f32(u.data_ptr(), sigma.data_ptr(), part.data_ptr(), eps.data_ptr() if S > 0 else None,
+                                          g_mu.data_ptr(), g_rho.data_ptr(), state.data_ptr(), J, S, D, float(lambda_),
+                                          _stream(g_mu))
+    _check(rc, "whvi_reparam_kl_philox")
+    return u, sigma, (part.sum(dim=1) if nblk > 1 else part[:, 0]), eps
 
 
 def wbar_bwd_supported(dtype: torch.dtype, d: int) -> bool:

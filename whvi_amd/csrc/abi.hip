@@ -82,7 +82,6 @@ namespace whvi {
 // i.e. the terms of kl_diag_normal(g_mu, g_sigma, 0, lambda) in the reference's argument convention
 // (sd1 is a standard deviation, sd2 = lambda a variance -- reproduced as is).
 // eps is an INPUT (drawn by torch: injectable for parity tests, graph-safe generator).
-constexpr int REPARAM_SAMPLES_PER_BLOCK = 8;
 
 // grid = (ceil(D/256), J, ceil(S/8)): blockIdx.z owns 8 MC samples so small-D layers with many samples still
 // fill the chip; the z == 0 blocks also write sigma, u[:, 0] and the KL partial sums.

@@ -13,6 +13,9 @@ int fail(int code, const char *fmt, const char *a = "", long long x = 0, long lo
 int after_launch(const char *what);
 int num_cu();
 
+// MC samples one block of the reparameterisation kernels covers (abi.hip, train_aux.hip)
+constexpr int REPARAM_SAMPLES_PER_BLOCK = 8;
+
 // Largest row one wavefront holds in registers: log2(VEC) + 6 lane bits + log2(Kmax): f32/i32 2+6+5 (K=32) = 13;
 // f16/bf16 3+6+4 (K=16) = 13; f64 1+6+5 (K=32) = 12.  Longer rows take the row kernel on 2^LOW-element pieces
 // plus high-bit passes (fwht_high_kernel).

@@ -34,6 +34,100 @@ reparam_kl_bwd_kernel(float *grad_mu, float *grad_rho, const float *gu, const fl
     grad_rho[p] = rho > 20.0f ? dsg : dsg * (1.0f / (1.0f + expf(-rho)));
 }
 
+// ---- in-kernel eps for the reparameterisation -----------------------------------------------
+// Philox4x32-10 (Salmon et al., SC'11; the generator family torch.randn uses on GPUs) keyed by a 64-bit seed,
+// counter = (element column, matrix << 16 | sample block, launch offset + call, offset high word); Box-Muller
+// turns each 4 x 32 bits into 4 standard normals.  The generator state lives in DEVICE memory,
+//     state[0] = seed,  state[1] = launch offset,  state[2] = blocks finished (scratch),
+// and the kernel advances it itself: every block bumps state[2] when it is done and the block that finishes
+// last moves the offset on (all other blocks have read it by then: they read it before they finish).  Nothing
+// about the draw is baked into the launch, so a captured hipGraph draws fresh eps on every replay.
+__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+        const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+        c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+
+__device__ __forceinline__ void normals4(const uint32_t (&x)[4], float (&z)[4])
+{
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const float u1 = ((float)(x[2 * p] >> 8) + 0.5f) * 5.9604644775390625e-8f;        // (0, 1), 24 bits
+        const float u2 = ((float)(x[2 * p + 1] >> 8) + 0.5f) * 5.9604644775390625e-8f;
+        const float rad = sqrtf(-2.0f * logf(u1));
+        float sn, cs;
+        sincosf(6.283185307179586f * u2, &sn, &cs);
+        z[2 * p] = rad * cs;
+        z[2 * p + 1] = rad * sn;
+    }
+}
+
+// same grid and outputs as reparam_kl_kernel, plus eps_out (J, S, D): the draw, kept for the backward pass
+__global__ void __launch_bounds__(256)
+reparam_kl_philox_kernel(float *u, float *sigma, float *kl_part, float *eps_out, const float *g_mu, const float *g_rho,
+                         unsigned long long *state, int S, int D, float lambda_)
+{
+    const int j = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool lead = blockIdx.z == 0;
+    const unsigned long long seed = state[0], offset = state[1];
+    float term = 0.0f;
+    if (i < D) {
+        const float mu = g_mu[(size_t)j * D + i], rho = g_rho[(size_t)j * D + i];
+        const float sg = rho > 20.0f ? rho : log1pf(expf(rho));
+        float *uj = u + (size_t)j * (S + 1) * D + i;
+        float *ej = eps_out + (size_t)j * S * D + i;
+        const int k0 = blockIdx.z * REPARAM_SAMPLES_PER_BLOCK;
+        float z[REPARAM_SAMPLES_PER_BLOCK];
+#pragma unroll
+        for (int call = 0; call < REPARAM_SAMPLES_PER_BLOCK / 4; ++call) {
+            const unsigned long long off = offset + (unsigned)call;
+            uint32_t c[4] = {(uint32_t)i, ((uint32_t)j << 16) | (uint32_t)blockIdx.z, (uint32_t)off, (uint32_t)(off >> 32)};
+            philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+            float n4[4];
+            normals4(c, n4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) z[4 * call + q] = n4[q];
+        }
+#pragma unroll
+        for (int q = 0; q < REPARAM_SAMPLES_PER_BLOCK; ++q) {
+            const int k = k0 + q;
+            if (k < S) {
+                ej[(size_t)k * D] = z[q];
+                uj[(size_t)(k + 1) * D] = sg * z[q];
+            }
+        }
+        if (lead) {
+            sigma[(size_t)j * D + i] = sg;
+            uj[0] = mu;
+            term = 0.5f * (logf(lambda_) - logf(sg) - 1.0f + sg / lambda_ + mu * (mu / lambda_));
+        }
+    }
+    __shared__ float wave_sum[4];
+    if (lead) {   // block-uniform
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) term += __shfl_down(term, off, 64);
+        if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = term;
+    }
+    __syncthreads();                      // every thread of the block has read the generator state by now
+    if (threadIdx.x == 0) {
+        if (lead) kl_part[(size_t)j * gridDim.x + blockIdx.x] = (wave_sum[0] + wave_sum[1]) + (wave_sum[2] + wave_sum[3]);
+        __threadfence();
+        const unsigned total = gridDim.x * gridDim.y * gridDim.z;
+        if (atomicAdd(reinterpret_cast<unsigned *>(state + 2), 1u) == total - 1) {      // the last block to finish
+            state[1] = offset + REPARAM_SAMPLES_PER_BLOCK / 4;
+            state[2] = 0;
+        }
+    }
+}
+
 // ---- Gaussian MNLL (src/likelihoods.py:18-29) ------------------------------------------------------------
 //   ld(e) = -0.5 z^2 - log(sigma) - 0.5 log(2 pi),  z = (y - y_hat) / sigma
 //   mnll  = scale * sum_e ld(e),  scale = -n / (m * n_mc)
@@ -128,6 +222,25 @@ int whvi_reparam_kl_bwd_f32(void *grad_mu, void *grad_rho, const void *grad_u, c
                        (const float *)grad_kl, (const float *)g_mu, (const float *)g_rho, (const float *)eps,
                        (const float *)sigma, (int)S, (int)D, lambda_);
     return after_launch("reparam_kl_bwd");
+}
+
+extern "C" __attribute__((visibility("default")))
+int whvi_reparam_kl_philox_f32(void *u, void *sigma, void *kl_part, void *eps_out, const void *g_mu, const void *g_rho,
+                               void *state, int64_t J, int64_t S, int64_t D, float lambda_, void *stream)
+{
+    g_err[0] = 0;
+    if (J < 0 || S < 0 || D < 1 || J > 65535 || S > 8 * 65535 || D > (1 << 30))
+        return fail(WHVI_ERR_ARG, "whvi_reparam_kl_philox: bad sizes%s (J=%lld, D=%lld)", "", J, D);
+    if (J == 0) return WHVI_OK;
+    if (!u || !sigma || !kl_part || !g_mu || !g_rho || !state || (S > 0 && !eps_out))
+        return fail(WHVI_ERR_ARG, "whvi_reparam_kl_philox: null pointer%s", "");
+    if ((uintptr_t)state & 7) return fail(WHVI_ERR_ALIGN, "whvi_reparam_kl_philox: %s pointer is not 8-byte aligned", "state");
+    if (!(lambda_ > 0.0f)) return fail(WHVI_ERR_ARG, "whvi_reparam_kl_philox: lambda must be positive%s", "");
+    const unsigned gz = (unsigned)((S + REPARAM_SAMPLES_PER_BLOCK - 1) / REPARAM_SAMPLES_PER_BLOCK);
+    hipLaunchKernelGGL(reparam_kl_philox_kernel, dim3((unsigned)((D + 255) / 256), (unsigned)J, gz ? gz : 1u), dim3(256),
+                       0, (hipStream_t)stream, (float *)u, (float *)sigma, (float *)kl_part, (float *)eps_out,
+                       (const float *)g_mu, (const float *)g_rho, (unsigned long long *)state, (int)S, (int)D, lambda_);
+    return after_launch("reparam_kl_philox");
 }
 
 extern "C" __attribute__((visibility("default"))) int whvi_gauss_mnll_blocks(int64_t total) { return (int)mnll_blocks(total); }

@@ -51,6 +51,17 @@ class WHVINetwork(nn.Module, WHVI):
     def kl(self):
         return sum([m.kl for m in self.sequential.children() if 'kl' in dir(m)])
 
+    def set_inkernel_rng(self, on: bool = True):
+        """Opt in to drawing eps inside the reparameterisation kernel for the batched MC passes on the GPU
+        (``whvi_reparam_kl_philox_f32``): one launch less per layer and pass, hipGraph-safe.  The
+        numbers then come from this library's Philox stream, not from ``torch.randn`` (seeded from torch's default
+        generator when a layer first draws); the per-sample loop mode is unaffected."""
+        for module in self.modules():
+            if hasattr(type(module), "inkernel_rng"):
+                module.inkernel_rng = bool(on)
+                module._rng_state = None
+        return self
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """(batch, in_dim) -> (batch, out_dim, n_samples): one stochastic pass per Monte-Carlo
         sample, samples stacked on the last axis (src/networks.py:36-54)."""

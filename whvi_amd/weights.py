@@ -29,7 +29,8 @@ from whvi_amd.fwht.cuda import FWHTFunction as fwht_cuda
 from whvi_amd.fwht.python import FWHTFunction as fwht_python
 from whvi_amd.fwht.python import WHT_matmul as wht_matmul
 
-__all__ = ["WHVISquarePow2Matrix", "WHVIStackedMatrix", "WHVIColumnMatrix", "WBarFunction", "ReparamKLFunction"]
+__all__ = ["WHVISquarePow2Matrix", "WHVIStackedMatrix", "WHVIColumnMatrix", "WBarFunction", "ReparamKLFunction",
+           "ReparamKLPhiloxFunction"]
 
 
 class WBarFunction(torch.autograd.Function):
@@ -145,6 +146,24 @@ class ReparamKLFunction(torch.autograd.Function):
         return grad_mu, grad_sigma * torch.sigmoid(g_rho), grad_eps, None
 
 
+class ReparamKLPhiloxFunction(torch.autograd.Function):
+    """``ReparamKLFunction`` with eps drawn inside the kernel (``whvi_reparam_kl_philox_f32``: Philox4x32-10 +
+    Box-Muller, generator state in device memory, hipGraph-safe).  Same outputs, same one-launch backward."""
+
+    @staticmethod
+    def forward(ctx, g_mu, g_rho, state, n_samples, lambda_):
+        from whvi_amd import _hip
+        u, sigma, kl, eps = _hip.reparam_kl_philox(g_mu, g_rho, n_samples, lambda_, state)
+        ctx.save_for_backward(g_mu, g_rho, eps, sigma)
+        ctx.lambda_ = float(lambda_)
+        return u, kl
+
+    @staticmethod
+    def backward(ctx, grad_u, grad_kl):
+        grad_mu, grad_rho, _, _ = ReparamKLFunction.backward(ctx, grad_u, grad_kl)   # (input 2 = the state: no grad)
+        return grad_mu, grad_rho, None, None, None
+
+
 def _mean_plus_rest(t, dim):
     """``t[0:1] + t[1:]`` along ``dim`` (the ``w_bar(g_mu) + w_bar(g_sigma * eps_k)`` sum of src/weights.py:93), written
     with ``split``: the same additions, but its backward is one ``cat`` instead of two zero-filled scatter copies
@@ -163,7 +182,24 @@ def _reparam(g_mu, g_rho, eps, lambda_):
     return torch.cat((g_mu.unsqueeze(1), sigma.unsqueeze(1) * eps), dim=1), None
 
 
+def _draw_and_reparam(module, g_mu, g_rho, n_samples, lambda_):
+    """(u (J, 1+S, D), kl) for a batched MC pass.  Default: one ``torch.randn(J, S, D)`` draw (the stream the
+    parity tests replay) followed by ``_reparam``.  With ``module.inkernel_rng`` on a GPU the draw happens inside
+    the reparameterisation kernel: one launch, graph-safe, this library's own Philox stream."""
+    J, D = g_mu.shape
+    if module.inkernel_rng and g_mu.device.type == "cuda" and g_mu.dtype == torch.float32:
+        from whvi_amd import _hip
+        state = getattr(module, "_rng_state", None)
+        if state is None or state.device != g_mu.device:
+            state = module._rng_state = _hip.new_rng_state(g_mu.device)
+        return ReparamKLPhiloxFunction.apply(g_mu, g_rho, state, n_samples, lambda_)
+    eps = torch.randn(J, n_samples, D, device=g_mu.device)
+    return _reparam(g_mu, g_rho, eps, lambda_)
+
+
 class WHVISquarePow2Matrix(nn.Module):
+    inkernel_rng = False      # opt-in: draw eps inside the reparameterisation kernel (batched MC passes on the GPU)
+
     def __init__(self, D, lambda_=1e-5, bias=False):
         """Square (D, D) WHVI matrix, D a power of two (src/weights.py:14-32).
 
@@ -264,13 +300,14 @@ class WHVISquarePow2Matrix(nn.Module):
         (shared input) or ``(n_samples, batch, D)``; returns ``(n_samples, batch, D)``.  Sample k is
         what ``forward`` computes with the k-th row of one ``randn(n_samples, D)`` draw: one fused
         launch builds every sample's weight matrix, one batched GEMM applies them."""
-        eps = torch.randn(n_samples, self.D, device=self.g_mu.device)
         self._mc_kl = None
         if self.exploit_diagonal:
+            eps = torch.randn(n_samples, self.D, device=self.g_mu.device)
             w = self._w_bar_diagonal(self.g_mu) + self._w_bar_diagonal(self.g_sigma * eps)   # (S, D)
             out = (x if x.dim() == 3 else x.unsqueeze(0)) * w.unsqueeze(1)
             return out + self.bias if self.bias is not None else out
-        u, kl = _reparam(self.g_mu.unsqueeze(0), self.g_rho.unsqueeze(0), eps.unsqueeze(0), self.lambda_)
+        # one randn(S, D) draw (or the in-kernel generator), softplus, g_sigma * eps and the KL terms
+        u, kl = _draw_and_reparam(self, self.g_mu.unsqueeze(0), self.g_rho.unsqueeze(0), n_samples, self.lambda_)
         u = u.squeeze(0)                                                          # (1 + S, D)
         self._mc_kl = None if kl is None else kl.squeeze(0)   # KL of this pass, for WHVINetwork.loss
         if u.device.type == "cuda":
@@ -283,6 +320,8 @@ class WHVISquarePow2Matrix(nn.Module):
 
 
 class WHVIStackedMatrix(nn.Module):
+    inkernel_rng = False      # see WHVISquarePow2Matrix
+
     def __init__(self, n_in, n_out, lambda_=1e-5, bias=False):
         """Arbitrary (n_out, n_in) matrix as a vertical stack of square power-of-two blocks
         (src/weights.py:112-133)."""
@@ -357,12 +396,11 @@ class WHVIStackedMatrix(nn.Module):
         ``[j, k]`` of one ``randn(stack, n_samples, D_in)`` draw."""
         S, J, D = n_samples, self.stack, self.D_in
         dev = self.weight_matrices[0].g_mu.device
-        eps = torch.randn(J, S, D, device=dev)
         s1 = torch.stack([m.s1 for m in self.weight_matrices])
         s2 = torch.stack([m.s2 for m in self.weight_matrices])
         g_mu = torch.stack([m.g_mu for m in self.weight_matrices])
         g_rho = torch.stack([m.g_rho for m in self.weight_matrices])
-        u, kl = _reparam(g_mu, g_rho, eps, self.lambda_)                            # (J, 1 + S, D)
+        u, kl = _draw_and_reparam(self, g_mu, g_rho, S, self.lambda_)               # (J, 1 + S, D)
         self._mc_kl = None if kl is None else kl.sum()
         if dev.type == "cuda":
             W = WBarFunction.apply(s1, u, s2, None, True)                           # (J, S, D, D), the sum in-kernel
@@ -392,6 +430,8 @@ class WHVIStackedMatrix(nn.Module):
 
 
 class WHVIColumnMatrix(nn.Module):
+    inkernel_rng = False      # see WHVISquarePow2Matrix
+
     def __init__(self, n_out, lambda_=1e-5, bias=False, transposed=False):
         """Column (n_out, 1) matrix -- or row (1, n) when ``transposed`` -- cut from a square
         sample (src/weights.py:212-228)."""
@@ -424,8 +464,7 @@ class WHVIColumnMatrix(nn.Module):
         (n_samples, batch, n_in) -> (n_samples, batch, n_out).  Only row 0 of every sampled square
         matrix is ever built."""
         sq = self.weight_submodule
-        eps = torch.randn(n_samples, sq.D, device=sq.g_mu.device)
-        u, kl = _reparam(sq.g_mu.unsqueeze(0), sq.g_rho.unsqueeze(0), eps.unsqueeze(0), sq.lambda_)
+        u, kl = _draw_and_reparam(self, sq.g_mu.unsqueeze(0), sq.g_rho.unsqueeze(0), n_samples, sq.lambda_)
         self._mc_kl = None if kl is None else kl.squeeze(0)
         g_tilde = _mean_plus_rest(u.squeeze(0), 0)                       # (S, D_adj): g_mu + g_sigma * eps
         if g_tilde.device.type == "cuda":
