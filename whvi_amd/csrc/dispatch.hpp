@@ -125,7 +125,7 @@ inline void launch_rows(void *dst, const void *src, int64_t n_chunks, int varian
                 // fall to 5.7: their waves share SIMDs and leave the butterflies microseconds apart); fp16 5.5 ->
                 // 6.2, bf16 5.0 -> 6.1, i32 5.8 -> 6.3 TB/s (tools/probe_stream_blocks.py)
                 static const bool exp_big_blocks = getenv("WHVI_STREAM_BIG_BLOCKS") != nullptr;   // A/B switch
-                if (exp_big_blocks || sizeof(T) == 8) WHVI_LAUNCH(POLICY_DPP, false, true, BIG);   // f64: 6.0 vs 5.8
+                if (exp_big_blocks || sizeof(T) == 8) WHVI_LAUNCH(POLICY_DPP, false, true, BIG);   // f64, 16 KiB tiles: 6.07 vs 5.93
                 else if constexpr (sizeof(T) == 2 && K * Elem<T>::VEC == 64)
                     // 16-bit storage: half the bytes per butterfly, so the DPP network's VALU time co-limits the
                     // stream (6.1 TB/s).  The LDS-staged network needs a third of the issue slots: fp16 6.4,
@@ -141,7 +141,12 @@ inline void launch_rows(void *dst, const void *src, int64_t n_chunks, int varian
             // 6.6-6.8 vs 6.5-6.7 TB/s at 128-256 MiB in place, 6.7 vs 5.3 at 32 MiB)
             else WHVI_LAUNCH(POLICY_DPP, false, false, 256);
         } else {
-            WHVI_LAUNCH(POLICY_DPP, false, false, 256);
+            // tiles of more than 64 data VGPRs (one row per wave: f32 D = 8192, f64 D = 4096): 256-thread blocks
+            // either way; streams get the non-temporal accesses and the store barrier as well
+            if (big && nt)
+                hipLaunchKernelGGL((fwht_rows_kernel<T, LOG2D, K, POLICY_DPP, false, true, 256, 1>),
+                                   dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, st, d, s, n_chunks, n_tiles);
+            else WHVI_LAUNCH(POLICY_DPP, false, false, 256);
         }
         return;
     }
