@@ -184,10 +184,10 @@ __device__ __forceinline__ void bfly(A &lo, A &hi)
 // the issue slots of every in-register stage.  Same IEEE adds/subs, so the bits do not change.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <typename A>
+template <typename A, bool PK = true>
 __device__ __forceinline__ void bfly2(A &lo0, A &lo1, A &hi0, A &hi1)
 {
-    if constexpr (std::is_same<A, float>::value) {
+    if constexpr (std::is_same<A, float>::value && PK) {
         f32x2 a = {lo0, lo1}, b = {hi0, hi1};
         f32x2 s = a + b, d = a - b;
         lo0 = s[0];
@@ -201,7 +201,11 @@ __device__ __forceinline__ void bfly2(A &lo0, A &lo1, A &hi0, A &hi1)
 }
 
 // One full FWHT of every 2^LOG2D-element row held in r[K][VEC] (layout above).
-template <typename A, int VEC, int K, int LOG2D, int POLICY>
+// PK: issue the in-register stages of f32 tiles as v_pk_add_f32 pairs.  Same bits either way.  Packed adds halve
+// the issue slots of those stages but want even-aligned register pairs: in the plain streaming kernel that costs
+// 38 VGPRs (145 vs 107 = 3 vs 4 waves per SIMD) and 1.5 % of the stream at D = 4096, so it passes PK = false; the
+// fused / weight kernels (more VALU work per byte) are faster with it.
+template <typename A, int VEC, int K, int LOG2D, int POLICY, bool PK = true>
 __device__ __forceinline__ void fwht_tile(A (&r)[K][VEC], const int lane)
 {
     constexpr int LV = ilog2(VEC);
@@ -222,7 +226,7 @@ __device__ __forceinline__ void fwht_tile(A (&r)[K][VEC], const int lane)
                 if constexpr (H >= 2) {
 #pragma unroll
                     for (int c = 0; c < VEC; c += 2)
-                        if ((c & H) == 0) bfly2(r[k][c], r[k][c + 1], r[k][c | H], r[k][(c | H) + 1]);
+                        if ((c & H) == 0) bfly2<A, PK>(r[k][c], r[k][c + 1], r[k][c | H], r[k][(c | H) + 1]);
                 } else {
 #pragma unroll
                     for (int c = 0; c < VEC; ++c)
@@ -279,7 +283,7 @@ __device__ __forceinline__ void fwht_tile(A (&r)[K][VEC], const int lane)
                         for (int c = 0; c < VEC; c += 2) {
                             swap_pair<W>(r[k][c], r[k | KH][c]);
                             swap_pair<W>(r[k][c + 1], r[k | KH][c + 1]);
-                            bfly2(r[k][c], r[k][c + 1], r[k | KH][c], r[k | KH][c + 1]);
+                            bfly2<A, PK>(r[k][c], r[k][c + 1], r[k | KH][c], r[k | KH][c + 1]);
                             if constexpr (!PAIRED) {
                                 swap_pair<W>(r[k][c], r[k | KH][c]);
                                 swap_pair<W>(r[k][c + 1], r[k | KH][c + 1]);
@@ -303,7 +307,7 @@ __device__ __forceinline__ void fwht_tile(A (&r)[K][VEC], const int lane)
                             if constexpr (VIA16) swap_pair<16>(r[k][c + h], r[k | KH][c + h]);
                             else if constexpr (VIA32) swap_pair<32>(r[k][c + h], r[k | KH][c + h]);
                         }
-                        bfly2(r[k][c], r[k][c + 1], r[k | KH][c], r[k | KH][c + 1]);
+                        bfly2<A, PK>(r[k][c], r[k][c + 1], r[k | KH][c], r[k | KH][c + 1]);
                     }
                 }
         }

@@ -201,7 +201,7 @@ fwht_rows_kernel(u32x4 *dst, const u32x4 *src, int64_t n_chunks, int64_t n_tiles
         if constexpr (POLICY == POLICY_LDS)
             fwht_tile_lds<A, VEC, K, LOG2D>(r, lane, reinterpret_cast<A *>(whvi_smem) + wave * lds_slab_floats<VEC, K>());
         else
-            fwht_tile<A, VEC, K, LOG2D, POLICY>(r, lane);
+            fwht_tile<A, VEC, K, LOG2D, POLICY, false>(r, lane);      // no packed adds here: see fwht_tile
     };
 
     auto load_tile = [&](int64_t tile, u32x4 (&raw)[K]) {
