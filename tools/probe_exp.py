@@ -5,7 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from whvi_amd import _hip
 
-x = torch.randn(1 << 20, 4096, device="cuda") * 2.0 ** -100
+LOG2D = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+x = (torch.randn(1 << 30 if LOG2D < 12 else 1 << 32, device="cuda") * 2.0 ** -100).view(-1, 1 << LOG2D)
 libs = {"prod": _hip.lib()}
 for path in sorted(glob.glob(os.path.join(os.path.dirname(_hip.LIB_PATH), "_exp", "libexp_*.so"))):
     L = ctypes.CDLL(path)
@@ -15,13 +16,13 @@ for path in sorted(glob.glob(os.path.join(os.path.dirname(_hip.LIB_PATH), "_exp"
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def ms(L, iters=6):
+def ms(L, iters=10):
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    L.whvi_fwht_f32(x.data_ptr(), x.data_ptr(), x.size(0), 12, st)
+    L.whvi_fwht_f32(x.data_ptr(), x.data_ptr(), x.size(0), LOG2D, st)
     torch.cuda.synchronize()
     s.record()
     for _ in range(iters):
-        L.whvi_fwht_f32(x.data_ptr(), x.data_ptr(), x.size(0), 12, st)
+        L.whvi_fwht_f32(x.data_ptr(), x.data_ptr(), x.size(0), LOG2D, st)
     e.record()
     torch.cuda.synchronize()
     x.mul_(0).add_(1e-30)
