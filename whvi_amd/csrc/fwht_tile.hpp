@@ -201,11 +201,11 @@ __device__ __forceinline__ void bfly2(A &lo0, A &lo1, A &hi0, A &hi1)
 }
 
 // One full FWHT of every 2^LOG2D-element row held in r[K][VEC] (layout above).
-// PK: issue the in-register stages of f32 tiles as v_pk_add_f32 pairs.  Same bits either way.  Packed adds halve
+// PK (bit mask: 1 = in-chunk stages, 2 = permlane-swap stages, 4 = k-bit stages): issue those stages of f32 tiles as v_pk_add_f32 pairs.  Same bits either way.  Packed adds halve
 // the issue slots of those stages but want even-aligned register pairs: in the plain streaming kernel that costs
 // 38 VGPRs (145 vs 107 = 3 vs 4 waves per SIMD) and 1.5 % of the stream at D = 4096, so it passes PK = false; the
 // fused / weight kernels (more VALU work per byte) are faster with it.
-template <typename A, int VEC, int K, int LOG2D, int POLICY, bool PK = true>
+template <typename A, int VEC, int K, int LOG2D, int POLICY, int PK = 7>
 __device__ __forceinline__ void fwht_tile(A (&r)[K][VEC], const int lane)
 {
     constexpr int LV = ilog2(VEC);
@@ -226,7 +226,7 @@ __device__ __forceinline__ void fwht_tile(A (&r)[K][VEC], const int lane)
                 if constexpr (H >= 2) {
 #pragma unroll
                     for (int c = 0; c < VEC; c += 2)
-                        if ((c & H) == 0) bfly2<A, PK>(r[k][c], r[k][c + 1], r[k][c | H], r[k][(c | H) + 1]);
+                        if ((c & H) == 0) bfly2<A, (PK & 1) != 0>(r[k][c], r[k][c + 1], r[k][c | H], r[k][(c | H) + 1]);
                 } else {
 #pragma unroll
                     for (int c = 0; c < VEC; ++c)
@@ -267,8 +267,10 @@ __device__ __forceinline__ void fwht_tile(A (&r)[K][VEC], const int lane)
 #pragma unroll
                         for (int c = 0; c < VEC; ++c)
                             if (k0 + g < K)
-                                r[k0 + g][c] = Bits<A>::add_folded(
-                                    Bits<A>::template partner_dpp<LB>(r[k0 + g][c]), r[k0 + g][c], t[g][c], upper);
+                            {
+                                A partner = Bits<A>::template partner_dpp<LB>(r[k0 + g][c]);
+                                r[k0 + g][c] = Bits<A>::add_folded(partner, r[k0 + g][c], t[g][c], upper);
+                            }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
@@ -283,7 +285,7 @@ __device__ __forceinline__ void fwht_tile(A (&r)[K][VEC], const int lane)
                         for (int c = 0; c < VEC; c += 2) {
                             swap_pair<W>(r[k][c], r[k | KH][c]);
                             swap_pair<W>(r[k][c + 1], r[k | KH][c + 1]);
-                            bfly2<A, PK>(r[k][c], r[k][c + 1], r[k | KH][c], r[k | KH][c + 1]);
+                            bfly2<A, (PK & 2) != 0>(r[k][c], r[k][c + 1], r[k | KH][c], r[k | KH][c + 1]);
                             if constexpr (!PAIRED) {
                                 swap_pair<W>(r[k][c], r[k | KH][c]);
                                 swap_pair<W>(r[k][c + 1], r[k | KH][c + 1]);
@@ -307,7 +309,7 @@ __device__ __forceinline__ void fwht_tile(A (&r)[K][VEC], const int lane)
                             if constexpr (VIA16) swap_pair<16>(r[k][c + h], r[k | KH][c + h]);
                             else if constexpr (VIA32) swap_pair<32>(r[k][c + h], r[k | KH][c + h]);
                         }
-                        bfly2<A, PK>(r[k][c], r[k][c + 1], r[k | KH][c], r[k | KH][c + 1]);
+                        bfly2<A, (PK & 4) != 0>(r[k][c], r[k][c + 1], r[k | KH][c], r[k | KH][c + 1]);
                     }
                 }
         }

@@ -171,7 +171,10 @@ __device__ __forceinline__ void tile_store_stream(u32x4 *tile_base, int lane, in
 // can be partial; its missing chunks belong to rows that do not exist (rows never straddle
 // tiles), so they are read as zero and never stored.
 template <typename T, int LOG2D, int K, int POLICY, bool PREFETCH, bool NT, int BLOCK = 256, int ALIGN = 0>
-__global__ void __launch_bounds__(BLOCK)
+#ifndef WHVI_ROWS_WAVES_PER_EU
+#define WHVI_ROWS_WAVES_PER_EU 1      // tuning hook (tools/probe_exp.py builds): minimum waves per SIMD to allocate for
+#endif
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WHVI_ROWS_WAVES_PER_EU)))
 fwht_rows_kernel(u32x4 *dst, const u32x4 *src, int64_t n_chunks, int64_t n_tiles)
 {
     using E = Elem<T>;
@@ -201,7 +204,10 @@ fwht_rows_kernel(u32x4 *dst, const u32x4 *src, int64_t n_chunks, int64_t n_tiles
         if constexpr (POLICY == POLICY_LDS)
             fwht_tile_lds<A, VEC, K, LOG2D>(r, lane, reinterpret_cast<A *>(whvi_smem) + wave * lds_slab_floats<VEC, K>());
         else
-            fwht_tile<A, VEC, K, LOG2D, POLICY, false>(r, lane);      // no packed adds here: see fwht_tile
+#ifndef WHVI_ROWS_PKMASK
+#define WHVI_ROWS_PKMASK 0
+#endif
+            fwht_tile<A, VEC, K, LOG2D, POLICY, WHVI_ROWS_PKMASK>(r, lane);      // no explicit packed adds here: see fwht_tile
     };
 
     auto load_tile = [&](int64_t tile, u32x4 (&raw)[K]) {

@@ -85,7 +85,7 @@ wbar_bwd_kernel(T *grad_u, T *part_s1, T *part_s2, const u32x4 *gw, const T *s1,
             for (int e = 0; e < VEC; ++e) r[k][e] = s1v * r[k][e];
         }
     }
-    fwht_tile<A, VEC, K, LOG2D, POLICY_DPP, false>(r, lane);       // g1
+    fwht_tile<A, VEC, K, LOG2D, POLICY_DPP, 0>(r, lane);       // g1
 
     A acc_u[NACC], acc_s2[NACC];
 #pragma unroll

@@ -64,7 +64,7 @@ wbar_fwd_kernel(u32x4 *dst, const T *s1, const T *u, const T *s2, const u32x4 *b
 #pragma unroll
         for (int e = 0; e < VEC; ++e) r[k][e] = (__builtin_popcount(i & (d0 + e)) & 1) ? -v : v;
     }
-    fwht_tile<A, VEC, K, LOG2D, POLICY_DPP, false>(r, lane);
+    fwht_tile<A, VEC, K, LOG2D, POLICY_DPP, 0>(r, lane);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
 #pragma unroll
