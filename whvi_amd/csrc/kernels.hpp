@@ -366,6 +366,9 @@ inline FastDiv make_fastdiv(uint32_t d)
 // one scalar per row.  EYE: src is not read; row i of each group is c[i] * e_i (the first group_rows
 // rows of torch.diag(s2), src/weights.py:73).  Every multiply is its own rounding (built with -ffp-contract=off), like
 // the reference's separate matmul_diag_left kernels (src/utils.py:4-12).
+#ifndef WHVI_FUSED_PKMASK
+#define WHVI_FUSED_PKMASK 3     // packed adds in the in-chunk and permlane stages, not the k-bit ones (tools/probe_exp_fused.py)
+#endif
 template <typename T, int LOG2D, int K, int AXIS, bool EYE, bool NT, int BLOCK, int POLICY = POLICY_DPP,
           bool STAGE_AC = false>
 __global__ void __launch_bounds__(BLOCK)
@@ -417,7 +420,7 @@ fused_shs_kernel(u32x4 *dst, const u32x4 *src, const T *a, const T *b, const T *
             fwht_tile_lds<A, VEC, K, LOG2D>(r, lane, reinterpret_cast<A *>(whvi_smem) + STAGED +
                                                          wave * lds_slab_floats<VEC, K>());
         else
-            fwht_tile<A, VEC, K, LOG2D, POLICY_DPP>(r, lane);
+            fwht_tile<A, VEC, K, LOG2D, POLICY_DPP, WHVI_FUSED_PKMASK>(r, lane);
     };
 
     const int64_t base = t * TILE;
