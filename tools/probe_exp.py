@@ -6,23 +6,25 @@ import torch
 from whvi_amd import _hip
 
 LOG2D = int(sys.argv[1]) if len(sys.argv) > 1 else 12
-x = (torch.randn(1 << 30 if LOG2D < 12 else 1 << 32, device="cuda") * 2.0 ** -100).view(-1, 1 << LOG2D)
+SFX = sys.argv[2] if len(sys.argv) > 2 else "f32"           # f32 | f16 | bf16 | i32
+DT = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16, "i32": torch.int32}[SFX]
+x = (torch.randn(1 << 30 if LOG2D < 12 else 1 << 32, device="cuda") * 2.0 ** -100).to(DT).view(-1, 1 << LOG2D)
 libs = {"prod": _hip.lib()}
 for path in sorted(glob.glob(os.path.join(os.path.dirname(_hip.LIB_PATH), "_exp", "libexp_*.so"))):
     L = ctypes.CDLL(path)
-    L.whvi_fwht_f32.restype = ctypes.c_int
-    L.whvi_fwht_f32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p]
+    getattr(L, 'whvi_fwht_' + SFX).restype = ctypes.c_int
+    getattr(L, 'whvi_fwht_' + SFX).argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p]
     libs[os.path.basename(path)[7:-3]] = L
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 def ms(L, iters=10):
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    L.whvi_fwht_f32(x.data_ptr(), x.data_ptr(), x.size(0), LOG2D, st)
+    getattr(L, 'whvi_fwht_' + SFX)(x.data_ptr(), x.data_ptr(), x.size(0), LOG2D, st)
     torch.cuda.synchronize()
     s.record()
     for _ in range(iters):
-        L.whvi_fwht_f32(x.data_ptr(), x.data_ptr(), x.size(0), LOG2D, st)
+        getattr(L, 'whvi_fwht_' + SFX)(x.data_ptr(), x.data_ptr(), x.size(0), LOG2D, st)
     e.record()
     torch.cuda.synchronize()
     x.mul_(0).add_(1e-30)
@@ -35,4 +37,4 @@ for rnd in range(5):
         res[k].append(ms(L))
 for k, v in res.items():
     v.sort()
-    print(f"{k:6s} median {v[len(v)//2]:.3f} ms  min {v[0]:.3f} ms  -> {x.numel()*8/v[len(v)//2]/1e9:.2f} TB/s", flush=True)
+    print(f"{k:6s} median {v[len(v)//2]:.3f} ms  min {v[0]:.3f} ms  -> {x.numel()*2*x.element_size()/v[len(v)//2]/1e9:.2f} TB/s", flush=True)
