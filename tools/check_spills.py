@@ -17,8 +17,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fP
          "-Rpass-analysis=kernel-resource-usage", "-c", "-o", "/dev/null"]
 
 
+EXTRA = {"fused_f32": ["-fno-slp-vectorize"]}      # per-unit flags, as in whvi_amd/csrc/Makefile
+
+
 def scan(unit):
-    out = subprocess.run(["/opt/rocm/bin/hipcc", *FLAGS, os.path.join(CSRC, unit + ".hip")],
+    out = subprocess.run(["/opt/rocm/bin/hipcc", *FLAGS, *EXTRA.get(unit, []), os.path.join(CSRC, unit + ".hip")],
                          capture_output=True, text=True).stderr
     bad, name, n = [], None, 0
     for line in out.splitlines():

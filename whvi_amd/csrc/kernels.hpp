@@ -367,7 +367,7 @@ inline FastDiv make_fastdiv(uint32_t d)
 // rows of torch.diag(s2), src/weights.py:73).  Every multiply is its own rounding (built with -ffp-contract=off), like
 // the reference's separate matmul_diag_left kernels (src/utils.py:4-12).
 #ifndef WHVI_FUSED_PKMASK
-#define WHVI_FUSED_PKMASK 3     // packed adds in the in-chunk and permlane stages, not the k-bit ones (tools/probe_exp_fused.py)
+#define WHVI_FUSED_PKMASK 2     // packed adds in the permlane stages only; the TU is built with -fno-slp-vectorize (Makefile)
 #endif
 template <typename T, int LOG2D, int K, int AXIS, bool EYE, bool NT, int BLOCK, int POLICY = POLICY_DPP,
           bool STAGE_AC = false>
