@@ -95,16 +95,21 @@ wbar_bwd_kernel(T *grad_u, T *part_s1, T *part_s2, const u32x4 *gw, const T *s1,
         const A uv0 = MEAN ? (A)u[(size_t)x.u0 * D + x.i] : (A)0;
         const A s2v = (A)s2[(size_t)x.j * D + x.i];
         A su = (A)0, ss = (A)0;
+        // H[i,d] = (-1)^popcount(i & d) with d = dbase + e, dbase a multiple of VEC: the parity splits into one term
+        // per chunk and one per in-chunk position, and the sign goes onto g1 once ((-g) * s == -(g * s) exactly)
+        bool par_e[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) par_e[e] = __builtin_popcount(x.i & (uint32_t)e) & 1;
 #pragma unroll
         for (int kk = 0; kk < KPR; ++kk) {
             const int k = n * KPR + kk;
-            const uint32_t dbase = chunk_col(k) * VEC;
+            const bool par_k = __builtin_popcount(x.i & (chunk_col(k) * VEC)) & 1;
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
-                const bool neg = __builtin_popcount(x.i & (dbase + e)) & 1;        // H[i,d] = -1
-                su += flip_if(r[k][e] * s2v, neg);
-                ss += flip_if(uv * r[k][e], neg);
-                if constexpr (MEAN) ss += flip_if(uv0 * r[k][e], neg);
+                const A g = flip_if(r[k][e], par_k != par_e[e]);
+                su += g * s2v;
+                ss += uv * g;
+                if constexpr (MEAN) ss += uv0 * g;
             }
         }
 #pragma unroll
