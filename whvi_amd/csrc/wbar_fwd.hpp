@@ -60,9 +60,10 @@ wbar_fwd_kernel(u32x4 *dst, const T *s1, const T *u, const T *s2, const u32x4 *b
         const A v = (A)u[(size_t)jk * D + i] * (A)s2[(size_t)j * D + i];
         s1v[k] = (A)s1[(size_t)j * D + i];
         base_row[k] = j * by_r.d + i;
-        const uint32_t d0 = chunk_col(k) * VEC;
+        // H[i,d] = (-1)^popcount(i & d), d = d0 + e with d0 a multiple of VEC: one parity per chunk, one per position
+        const bool par_k = __builtin_popcount(i & (chunk_col(k) * VEC)) & 1;
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) r[k][e] = (__builtin_popcount(i & (d0 + e)) & 1) ? -v : v;
+        for (int e = 0; e < VEC; ++e) r[k][e] = (par_k != (bool)(__builtin_popcount(i & (uint32_t)e) & 1)) ? -v : v;
     }
     fwht_tile<A, VEC, K, LOG2D, POLICY_DPP, 0>(r, lane);
 #pragma unroll
