@@ -3,7 +3,8 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from whvi_amd import _hip
-rows, d = 1 << 18, 4096
+d = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+rows = (1 << 30) // d
 for name, make in (("f32 zeros", lambda: torch.zeros(rows, d, device="cuda")),
                    ("f32 randn", lambda: torch.randn(rows, d, device="cuda") * 1e-3),
                    ("i32 zeros", lambda: torch.zeros(rows, d, device="cuda", dtype=torch.int32)),
