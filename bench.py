@@ -224,7 +224,7 @@ def _extra_sweep(device):
         d = 1 << log2d
         rows = (1 << 32) // (4 * d)
         x = torch.randn(rows, d, device=device) * 2.0 ** -64
-        out[f"D={d}"] = _rate(rows, d, 4, event_ms(lambda: _hip.fwht_rows(x, out=x)))
+        out[f"D={d}"] = _rate(rows, d, 4, event_ms(lambda: _hip.fwht_rows(x, out=x), iters=10, warm=10))
         del x
     return out
 
