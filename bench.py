@@ -189,6 +189,17 @@ def cpu_baseline(log2d, target_s=25.0):
     t0 = time.perf_counter()
     run(x)
     dt = time.perf_counter() - t0
+    # BASELINE config 1 (benchmarks/walsh.py shape): D = 512, batch 1024, on the host
+    c1 = None
+    try:
+        x1 = torch.randn(1024, 512, generator=g)
+        run(x1)
+        t1 = time.perf_counter()
+        for _ in range(3):
+            run(x1)
+        c1 = {"reference_ms": round((time.perf_counter() - t1) / 3 * 1e3, 3)}
+    except Exception as err:
+        c1 = {"error": repr(err)}
     native = None
     try:   # the build's own host-tensor FWHT (libwhvi_cpu.so, OpenMP over rows), same rows: the "fair" CPU number
         import fwht_cpp
@@ -197,12 +208,18 @@ def cpu_baseline(log2d, target_s=25.0):
         t1 = time.perf_counter()
         fwht_cpp.forward(xs)
         dn = time.perf_counter() - t1
+        if c1 is not None and "error" not in c1:
+            fwht_cpp.forward(x1)
+            t2 = time.perf_counter()
+            for _ in range(3):
+                fwht_cpp.forward(x1)
+            c1["native_openmp_library_ms"] = round((time.perf_counter() - t2) / 3 * 1e3, 3)
         native = {"Gtransforms_per_s": xs.size(0) / dn / 1e9, "GB_per_s_algorithmic": xs.numel() * 8 / dn / 1e9,
                   "threads": os.cpu_count(), "sample": f"{xs.size(0)} rows of D={d} fp32, out of place"}
     except Exception as err:
         native = {"error": repr(err)}
     return {"value": rows / dt / 1e9, "unit": "Gtransforms/s", "cores": cores, "kind": kind,
-            "native_openmp_library": native,
+            "native_openmp_library": native, "config1_D512_batch1024_host": c1,
             "sample": f"{rows} rows of D={d} fp32 (same row shape as the GPU workload), one call, {dt:.1f} s; "
                       + ("reference src/fwht/cpp/fwht.cpp compiled into oracle/_ref, "
                          f"{cores} torch threads of {os.cpu_count()} host CPUs" if kind == "reference"
