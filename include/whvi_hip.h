@@ -165,11 +165,16 @@ int whvi_reparam_kl_f32(void *u, void *sigma, void *kl_part, const void *g_mu, c
  * `base` (J, R, D), optional: a matrix added to every sample's matrix in the epilogue -- with base =
  * w_bar(g_mu) from a first call this is `w_bar(g_mu) + w_bar(g_sigma * eps_k)` of src/weights.py:93 without a
  * separate read-modify-write pass over all weight matrices.
- *   s1, s2 : (J, D)     u : (J, S, D)     dst : (J, S, R, D)     log2d in [2, 13] (f32) / [1, 12] (f64) */
+ *   s1, s2 : (J, D)     dst : (J, S, R, D)     log2d in [2, 13] (f32) / [1, 12] (f64)
+ *   u : (J, u_group, D); matrix (j, k) uses row u_first + k of group j.  u_group = S, u_first = 0 is the plain
+ *       (J, S, D) layout; with the (J, 1 + S, D) buffer of whvi_reparam_kl the mean call passes S = 1, u_first = 0 and
+ *       the per-sample call u_first = 1, both with u_group = 1 + S_samples -- no slicing copies. */
 int whvi_wbar_fwd_f32(void *dst, const void *s1, const void *u, const void *s2, const void *base,
-                      int64_t J, int64_t S, int64_t R, int32_t log2d, void *stream);
+                      int64_t J, int64_t S, int64_t R, int32_t log2d, int64_t u_group, int64_t u_first,
+                      void *stream);
 int whvi_wbar_fwd_f64(void *dst, const void *s1, const void *u, const void *s2, const void *base,
-                      int64_t J, int64_t S, int64_t R, int32_t log2d, void *stream);
+                      int64_t J, int64_t S, int64_t R, int32_t log2d, int64_t u_group, int64_t u_first,
+                      void *stream);
 
 /* Backward of the weight construction in ONE launch: reads the incoming gradient once, writes three scalars per
  * row.  The reference obtains the same quantities from autograd over its op chain (matmul_diag_left backward,

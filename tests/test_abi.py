@@ -59,11 +59,12 @@ def test_argument_checks_of_the_training_step_entry_points():
     buf = (ctypes.c_char * 512)()
     p16 = (ctypes.addressof(buf) + 15) & ~15
     i64x3 = ctypes.c_int64 * 3
-    assert L.whvi_wbar_fwd_f32(p16, p16, p16, p16, None, 1, 1, 4, 1, None) == -2 and "supported range" in _hip.last_error()
-    assert L.whvi_wbar_fwd_f32(p16, p16, p16, p16, None, 1, 1, 9, 3, None) == -1 and "exceeds D" in _hip.last_error()
-    assert L.whvi_wbar_fwd_f64(None, p16, p16, p16, None, 1, 1, 2, 1, None) == -1 and "null" in _hip.last_error()
-    assert L.whvi_wbar_fwd_f32(p16 + 4, p16, p16, p16, None, 1, 1, 4, 2, None) == -3
-    assert L.whvi_wbar_fwd_f32(None, None, None, None, None, 0, 3, 4, 2, None) == 0            # no matrices
+    assert L.whvi_wbar_fwd_f32(p16, p16, p16, p16, None, 1, 1, 4, 1, 1, 0, None) == -2 and "supported range" in _hip.last_error()
+    assert L.whvi_wbar_fwd_f32(p16, p16, p16, p16, None, 1, 1, 9, 3, 1, 0, None) == -1 and "exceeds D" in _hip.last_error()
+    assert L.whvi_wbar_fwd_f64(None, p16, p16, p16, None, 1, 1, 2, 1, 1, 0, None) == -1 and "null" in _hip.last_error()
+    assert L.whvi_wbar_fwd_f32(p16 + 4, p16, p16, p16, None, 1, 1, 4, 2, 1, 0, None) == -3
+    assert L.whvi_wbar_fwd_f32(p16, p16, p16, p16, None, 1, 2, 4, 2, 2, 1, None) == -1 and "u_group" in _hip.last_error()
+    assert L.whvi_wbar_fwd_f32(None, None, None, None, None, 0, 3, 4, 2, 3, 0, None) == 0            # no matrices
     assert L.whvi_wbar_bwd_f32(p16, p16, p16, p16, p16, p16, p16, 1, 1, 4, 14, 0, None) == -2
     assert L.whvi_wbar_bwd_f32(p16, p16, p16, p16, p16, p16, p16, 1, 1, 4, 2, 8, None) == -1 and "flags" in _hip.last_error()
     assert L.whvi_wbar_bwd_f64(p16, p16, p16, None, p16, p16, p16, 1, 1, 2, 1, 0, None) == -1

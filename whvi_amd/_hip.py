@@ -80,7 +80,7 @@ def _declare_f3(lib):
         fn.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, ctypes.c_int32, ctypes.c_int32, vp]
         fn = getattr(lib, "whvi_wbar_fwd_" + sfx)
         fn.restype = ctypes.c_int
-        fn.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, ctypes.c_int32, vp]
+        fn.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, ctypes.c_int32, i64, i64, vp]
 
 
 def lib():
@@ -301,13 +301,18 @@ def wbar_bwd_supported(dtype: torch.dtype, d: int) -> bool:
     return dtype == torch.float64 and 2 <= d <= 4096
 
 
-def wbar_fwd(s1: torch.Tensor, u: torch.Tensor, s2: torch.Tensor, rows: int = None, base: torch.Tensor = None):
-    """One launch: W (J, S, R, D) with W[j,k] = the first R rows of S1_j fwht(diag(u[j,k]) fwht(diag(s2_j))), plus
-    ``base`` (J, R, D) when given; see whvi_wbar_fwd_f32 in include/whvi_hip.h."""
+def wbar_fwd(s1: torch.Tensor, u: torch.Tensor, s2: torch.Tensor, rows: int = None, base: torch.Tensor = None,
+             first: int = 0, count: int = None):
+    """One launch: W (J, S, R, D) with W[j,k] = the first R rows of S1_j fwht(diag(u[j, first + k]) fwht(diag(s2_j))),
+    k < S = ``count`` (default: all rows of ``u`` from ``first`` on), plus ``base`` (J, R, D) when given; see
+    whvi_wbar_fwd_f32 in include/whvi_hip.h."""
     if u.device.type != "cuda" or u.dtype not in (torch.float32, torch.float64):
         raise RuntimeError("wbar_fwd: float32 / float64 CUDA tensors only")
-    J, S, D = u.shape
+    J, G, D = u.shape
+    S = G - first if count is None else int(count)
     R = D if rows is None else int(rows)
+    if first < 0 or S < 0 or first + S > G:
+        raise RuntimeError("wbar_fwd: rows first .. first + count do not fit u")
     if tuple(s1.shape) != (J, D) or tuple(s2.shape) != (J, D) or (base is not None and tuple(base.shape) != (J, R, D)):
         raise RuntimeError("wbar_fwd: operand shapes do not match u")
     if not (s1.dtype == s2.dtype == u.dtype) or (base is not None and base.dtype != u.dtype):
@@ -318,7 +323,7 @@ def wbar_fwd(s1: torch.Tensor, u: torch.Tensor, s2: torch.Tensor, rows: int = No
     fn = getattr(lib(), "whvi_wbar_fwd_" + _DTYPE_SUFFIX[u.dtype])
     with _OnDevice(u.device):
         rc = fn(out.data_ptr(), s1.data_ptr(), u.data_ptr(), s2.data_ptr(), None if base is None else base.data_ptr(),
-                J, S, R, D.bit_length() - 1, _stream(u))
+                J, S, R, D.bit_length() - 1, G, int(first), _stream(u))
     _check(rc, "whvi_wbar_fwd")
     return out
 

@@ -13,11 +13,13 @@
 
 namespace whvi {
 
-// rows are (J, S, R) x D; s1 / s2 are (J, D), u is (J, S, D); base is (J, R, D) or null
+// rows are (J, S, R) x D; s1 / s2 are (J, D); matrix (j, k) reads row j * u_group + u_first + k of u (so a
+// (J, 1 + S, D) buffer serves both the mean call -- u_first = 0, S = 1 -- and the per-sample call -- u_first = 1);
+// base is (J, R, D) or null
 template <typename T, int LOG2D, int K, bool NT>
 __global__ void __launch_bounds__(256)
 wbar_fwd_kernel(u32x4 *dst, const T *s1, const T *u, const T *s2, const u32x4 *base, int64_t n_chunks,
-                int64_t n_tiles, uint32_t n_rows, FastDiv by_r, FastDiv by_s)
+                int64_t n_tiles, uint32_t n_rows, FastDiv by_r, FastDiv by_s, uint32_t u_group, uint32_t u_first)
 {
     using E = Elem<T>;
     using A = typename E::acc;
@@ -57,7 +59,8 @@ wbar_fwd_kernel(u32x4 *dst, const T *s1, const T *u, const T *s2, const u32x4 *b
         const uint32_t jk = by_r.div(row);
         const uint32_t i = row - jk * by_r.d;
         const uint32_t j = by_s.div(jk);
-        const A v = (A)u[(size_t)jk * D + i] * (A)s2[(size_t)j * D + i];
+        const uint32_t urow = j * u_group + u_first + (jk - j * by_s.d);
+        const A v = (A)u[(size_t)urow * D + i] * (A)s2[(size_t)j * D + i];
         s1v[k] = (A)s1[(size_t)j * D + i];
         base_row[k] = j * by_r.d + i;
         // H[i,d] = (-1)^popcount(i & d), d = d0 + e with d0 a multiple of VEC: one parity per chunk, one per position
@@ -90,7 +93,7 @@ wbar_fwd_kernel(u32x4 *dst, const T *s1, const T *u, const T *s2, const u32x4 *b
 
 template <typename T, int LOG2D>
 inline void launch_wbar_fwd(void *dst, const void *s1, const void *u, const void *s2, const void *base, int64_t rows,
-                            int64_t S, int64_t R, hipStream_t st)
+                            int64_t S, int64_t R, int64_t u_group, int64_t u_first, hipStream_t st)
 {
     constexpr int K = pick_k<T, LOG2D>();
     constexpr int VEC = Elem<T>::VEC;
@@ -101,7 +104,7 @@ inline void launch_wbar_fwd(void *dst, const void *s1, const void *u, const void
 #define WHVI_FWD(NT)                                                                                        \
     hipLaunchKernelGGL((wbar_fwd_kernel<T, LOG2D, K, NT>), dim3(grid), dim3(256), 0, st, (u32x4 *)dst,       \
                        (const T *)s1, (const T *)u, (const T *)s2, (const u32x4 *)base, n_chunks, n_tiles,  \
-                       (uint32_t)rows, dr, ds)
+                       (uint32_t)rows, dr, ds, (uint32_t)u_group, (uint32_t)u_first)
     if (n_chunks * 16 >= NT_MIN_BYTES) WHVI_FWD(true);
     else WHVI_FWD(false);
 #undef WHVI_FWD
@@ -109,7 +112,7 @@ inline void launch_wbar_fwd(void *dst, const void *s1, const void *u, const void
 
 template <typename T>
 inline int wbar_fwd_dispatch(void *dst, const void *s1, const void *u, const void *s2, const void *base, int64_t J,
-                             int64_t S, int64_t R, int32_t log2d, void *stream)
+                             int64_t S, int64_t R, int32_t log2d, int64_t u_group, int64_t u_first, void *stream)
 {
     constexpr int LV = ilog2(Elem<T>::VEC);
     g_err[0] = 0;
@@ -118,6 +121,8 @@ inline int wbar_fwd_dispatch(void *dst, const void *s1, const void *u, const voi
         return fail(WHVI_ERR_SIZE, "whvi_wbar_fwd: log2(D)%s = %lld is outside the supported range [%lld, ...]", "",
                     log2d, LV);
     if (R > ((int64_t)1 << log2d)) return fail(WHVI_ERR_ARG, "whvi_wbar_fwd: R%s = %lld exceeds D", "", R);
+    if (u_first < 0 || u_group < u_first + S || u_group >= ((int64_t)1 << 31))
+        return fail(WHVI_ERR_ARG, "whvi_wbar_fwd: u_group%s = %lld does not hold rows u_first .. u_first + S", "", u_group);
     const int64_t rows = J * S * R;
     if (rows == 0) return WHVI_OK;
     if (rows >= ((int64_t)1 << 32)) return fail(WHVI_ERR_SIZE, "whvi_wbar_fwd: rows are indexed with 32 bits%s", "");
@@ -128,7 +133,7 @@ inline int wbar_fwd_dispatch(void *dst, const void *s1, const void *u, const voi
 #define WHVI_CASE(L)                                                                                       \
     case L:                                                                                                \
         if constexpr (L >= LV && L <= max_single_pass_log2d<T>())                                          \
-            launch_wbar_fwd<T, L>(dst, s1, u, s2, base, rows, S, R, st);                                    \
+            launch_wbar_fwd<T, L>(dst, s1, u, s2, base, rows, S, R, u_group, u_first, st);                                    \
         break;
     switch (log2d) {
         WHVI_CASE(1) WHVI_CASE(2) WHVI_CASE(3) WHVI_CASE(4) WHVI_CASE(5) WHVI_CASE(6) WHVI_CASE(7)

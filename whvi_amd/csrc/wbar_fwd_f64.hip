@@ -4,7 +4,7 @@
 
 extern "C" __attribute__((visibility("default")))
 int whvi_wbar_fwd_f64(void *dst, const void *s1, const void *u, const void *s2, const void *base, int64_t J, int64_t S,
-                      int64_t R, int32_t log2d, void *stream)
+                      int64_t R, int32_t log2d, int64_t u_group, int64_t u_first, void *stream)
 {
-    return whvi::wbar_fwd_dispatch<double>(dst, s1, u, s2, base, J, S, R, log2d, stream);
+    return whvi::wbar_fwd_dispatch<double>(dst, s1, u, s2, base, J, S, R, log2d, u_group, u_first, stream);
 }
