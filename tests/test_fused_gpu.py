@@ -625,3 +625,37 @@ def test_inkernel_rng_in_the_network_and_under_hipgraph(hip_lib):
     # every layer's generator moved on
     states = [m._rng_state for m in net.modules() if getattr(m, "_rng_state", None) is not None]
     assert len(states) == 3 and all(int(s[1]) > 0 and int(s[2]) == 0 for s in states)
+
+
+def test_packed_stacked_layer_on_gpu(monkeypatch, hip_lib):
+    """``pack_parameters()`` on the GPU: same outputs and gradients as the reference layout for the same eps
+    (loop and batched paths), checkpoint keys unchanged."""
+    import copy
+    torch.manual_seed(11)
+    plain = WHVILinear(13, 128, lambda_=0.5, bias=True)
+    with torch.no_grad():
+        for name, p in plain.named_parameters():
+            if name.endswith("g_mu") or name.endswith("s1") or name.endswith("s2"):
+                p.copy_(torch.randn(p.shape) * 0.4)
+    packed = copy.deepcopy(plain)
+    packed.weight_submodule.pack_parameters()
+    plain, packed = plain.to(DEV), packed.to(DEV)
+    sub = packed.weight_submodule
+    assert set(packed.state_dict()) == set(plain.state_dict()) and len(list(packed.parameters())) == 5
+    assert sub.packed_s1.device.type == "cuda" and sub.weight_matrices[3].s1.device.type == "cuda"
+    eps = [np.random.default_rng(40 + i).standard_normal(sub.D_in).astype(np.float32) for i in range(sub.stack)]
+    x = torch.randn(9, 13, device=DEV)
+    for use_mc in (False, True):
+        res = []
+        for layer in (plain, packed):
+            layer.zero_grad()
+            monkeypatch.setattr(torch, "randn", ReplayRandn(eps))
+            y = layer.weight_submodule.forward_mc(x, 1)[0] if use_mc else layer(x)
+            monkeypatch.undo()
+            (y.square().sum() + layer.kl).backward()
+            res.append(y.detach())
+        assert torch.equal(res[0], res[1])
+        for name in ("s1", "s2", "g_mu", "g_rho"):
+            want = torch.stack([getattr(m, name).grad for m in plain.weight_submodule.weight_matrices])
+            got = getattr(sub, "packed_" + name).grad
+            assert float((got - want).abs().max()) <= 1e-6 * float(want.abs().max()), (use_mc, name)

@@ -349,3 +349,73 @@ def test_src_alias_package_matches_reference_import_paths():
         m = importlib.import_module(mod)
         for n in names:
             assert hasattr(m, n), (mod, n)
+
+
+# ---- opt-in packed parameter layout of stacked layers ---------------------------------------------------
+@pytest.mark.parametrize("n_in,n_out", [(3, 16), (5, 7), (13, 128), (100, 33)])
+def test_packed_stacked_layer_is_the_same_layer(n_in, n_out, monkeypatch):
+    """``pack_parameters()``: 4 parameter tensors instead of 4 * stack, identical forward / KL / gradients for the
+    same eps, and ``state_dict`` in the reference's per-sub-matrix format both ways (also after deepcopy / pickle)."""
+    import copy
+    import io
+    torch.manual_seed(n_in + n_out)
+    plain = WHVILinear(n_in, n_out, lambda_=0.5, bias=True)
+    with torch.no_grad():
+        for name, p in plain.named_parameters():
+            if name.endswith("g_mu") or name.endswith("s1") or name.endswith("s2"):
+                p.copy_(torch.randn(p.shape) * 0.4)
+    packed = copy.deepcopy(plain)
+    packed.weight_submodule.pack_parameters()
+    sub = packed.weight_submodule
+    assert len(list(packed.parameters())) == 5 and len(list(plain.parameters())) == 4 * sub.stack + 1
+    assert list(packed.state_dict().keys()) and set(packed.state_dict()) == set(plain.state_dict())
+    for k, v in plain.state_dict().items():
+        assert torch.equal(packed.state_dict()[k], v), k
+    eps = [np.random.default_rng(3 + i).standard_normal(sub.D_in).astype(np.float32) for i in range(sub.stack)]
+    x = torch.randn(6, n_in)
+    outs = []
+    for layer in (plain, packed):
+        for use_mc in (False, True):
+            layer.zero_grad()
+            monkeypatch.setattr(torch, "randn", ReplayRandn(eps))
+            y = layer.weight_submodule.forward_mc(x, 1)[0] if use_mc else layer(x)
+            monkeypatch.undo()
+            (y.square().sum() + layer.kl).backward()
+            sd = layer.state_dict(keep_vars=True)
+            grads = {k: None for k in sd}
+            if layer is plain:
+                grads = {k: v.grad.clone() for k, v in sd.items()}
+            else:
+                for name in ("s1", "s2", "g_mu", "g_rho"):
+                    g = getattr(sub, "packed_" + name).grad
+                    for j in range(sub.stack):
+                        grads[f"weight_submodule.weight_matrices.{j}.{name}"] = g[j].clone()
+                grads["weight_submodule.bias"] = sub.bias.grad.clone()
+            outs.append((y.detach().clone(), float(layer.kl), grads))
+    for a, b in ((outs[0], outs[2]), (outs[1], outs[3])):
+        assert torch.equal(a[0], b[0]) and a[1] == b[1]
+        for k in a[2]:
+            assert torch.allclose(a[2][k], b[2][k], rtol=1e-6, atol=1e-7), k
+    # checkpoints interchange in both directions, strictly
+    fresh_plain = WHVILinear(n_in, n_out, lambda_=0.5, bias=True)
+    fresh_plain.load_state_dict(packed.state_dict())
+    fresh_packed = WHVILinear(n_in, n_out, lambda_=0.5, bias=True)
+    fresh_packed.weight_submodule.pack_parameters()
+    fresh_packed.load_state_dict(plain.state_dict())
+    for k, v in plain.state_dict().items():
+        assert torch.equal(fresh_plain.state_dict()[k], v) and torch.equal(fresh_packed.state_dict()[k], v)
+    with pytest.raises(RuntimeError, match="Missing key"):
+        fresh_packed.load_state_dict({k: v for k, v in plain.state_dict().items() if not k.endswith("0.s1")})
+    # deepcopy and pickle keep the sub-matrix views bound to their own parent
+    twin = copy.deepcopy(packed)
+    with torch.no_grad():
+        twin.weight_submodule.packed_s1.add_(1.0)
+    assert torch.equal(twin.weight_submodule.weight_matrices[0].s1, twin.weight_submodule.packed_s1[0])
+    assert not torch.equal(twin.weight_submodule.weight_matrices[0].s1, packed.weight_submodule.weight_matrices[0].s1)
+    buf = io.BytesIO()
+    torch.save(packed, buf)
+    buf.seek(0)
+    loaded = torch.load(buf, weights_only=False)
+    last = sub.stack - 1
+    assert torch.equal(loaded.weight_submodule.weight_matrices[last].g_rho, packed.weight_submodule.packed_g_rho[last])
+    assert loaded(x * 0).shape == (6, n_out) and torch.equal(loaded.weight_submodule.packed_s2, packed.weight_submodule.packed_s2)

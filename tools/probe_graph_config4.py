@@ -11,8 +11,11 @@ dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 net = WHVIRegression([WHVILinear(3, 1024), nn.ReLU(), WHVILinear(1024, 1024), nn.ReLU(), WHVILinear(1024, 1)],
                      train_samples=1).to(dev).train()
-if len(sys.argv) > 1 and sys.argv[1] == "philox":
+if "philox" in sys.argv[1:]:
     net.set_inkernel_rng(True)
+if "packed" in sys.argv[1:]:
+    net.pack_parameters()          # 4 parameter tensors per stacked layer instead of 4 * stack
+print(f"{len(list(net.parameters()))} parameter tensors", flush=True)
 x, y = torch.randn(256, 3, device=dev), torch.randn(256, 1, device=dev)
 opt = torch.optim.Adam(net.parameters(), lr=1e-3, capturable=True)
 
@@ -23,14 +26,14 @@ def eager():
     opt.step()
 
 
-for _ in range(3):
+for _ in range(15):
     eager()
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-for _ in range(10):
+for _ in range(30):
     eager()
 torch.cuda.synchronize()
-print(f"eager: {(time.perf_counter() - t0) / 10 * 1e3:.2f} ms per step", flush=True)
+print(f"eager: {(time.perf_counter() - t0) / 30 * 1e3:.2f} ms per step", flush=True)
 step = GraphedTrainStep(net, opt, x, y, n=45730)
 l0 = float(step(x, y))
 for _ in range(5):

@@ -51,6 +51,15 @@ class WHVINetwork(nn.Module, WHVI):
     def kl(self):
         return sum([m.kl for m in self.sequential.children() if 'kl' in dir(m)])
 
+    def pack_parameters(self):
+        """Opt in to the packed parameter layout of every stacked layer (``WHVIStackedMatrix.pack_parameters``):
+        ``4 * stack`` parameter tensors per layer become 4, checkpoints keep the reference's keys.  Call it before
+        creating the optimizer."""
+        for module in self.modules():
+            if hasattr(module, "pack_parameters") and module is not self:
+                module.pack_parameters()
+        return self
+
     def set_inkernel_rng(self, on: bool = True):
         """Opt in to drawing eps inside the reparameterisation kernel for the batched MC passes on the GPU
         (``whvi_reparam_kl_philox_f32``): one launch less per layer and pass, hipGraph-safe.  The

@@ -319,6 +319,27 @@ class WHVISquarePow2Matrix(nn.Module):
         return out + self.bias if self.bias is not None else out
 
 
+_PACKED_NAMES = ("s1", "s2", "g_mu", "g_rho")
+
+
+class _PackedSubMatrix(WHVISquarePow2Matrix):
+    """A sub-matrix of a packed ``WHVIStackedMatrix``: same methods, but its four vectors are row ``_index`` of the
+    parent's packed parameters (views made on access, so autograd and ``.to()`` go through the parent)."""
+
+    def _row(self, name):
+        return getattr(self._packed_parent(), "packed_" + name)[self._index]
+
+    def __getstate__(self):                    # the back-reference is a weakref: rebuilt by the parent's __setstate__
+        state = self.__dict__.copy()
+        state.pop("_packed_parent", None)
+        return state
+
+    s1 = property(lambda self: self._row("s1"))
+    s2 = property(lambda self: self._row("s2"))
+    g_mu = property(lambda self: self._row("g_mu"))
+    g_rho = property(lambda self: self._row("g_rho"))
+
+
 class WHVIStackedMatrix(nn.Module):
     inkernel_rng = False      # see WHVISquarePow2Matrix
 
@@ -333,6 +354,84 @@ class WHVIStackedMatrix(nn.Module):
         self.weight_matrices = nn.ModuleList(
             [WHVISquarePow2Matrix(self.D_in, lambda_=lambda_) for _ in range(self.stack)])
         self.bias = nn.Parameter(torch.zeros(1, self.D_out)) if bias else None
+        self._packed = False
+
+    # ---- opt-in packed parameter layout -------------------------------------------------------------------
+    def pack_parameters(self):
+        """Replace the ``4 * stack`` per-sub-matrix parameter vectors (the reference's layout, src/weights.py:130-132)
+        by four ``(stack, D_in)`` parameters ``packed_s1 / packed_s2 / packed_g_mu / packed_g_rho``.
+
+        Same values, same forward / backward arithmetic, and ``state_dict()`` / ``load_state_dict()`` keep the
+        reference's per-sub-matrix keys (``weight_matrices.<j>.s1`` ...), so checkpoints interchange in both
+        directions.  What changes is ``parameters()`` / ``named_parameters()``: 4 tensors instead of ``4 * stack``,
+        which is what an eager training step of e.g. ``WHVILinear(3, 1024)`` (1024 parameter tensors) is bound by.
+        Call it before creating the optimizer."""
+        if self._packed:
+            return self
+        for name in _PACKED_NAMES:
+            with torch.no_grad():
+                packed = torch.stack([getattr(m, name) for m in self.weight_matrices]).contiguous()
+            self.register_parameter("packed_" + name, nn.Parameter(packed))
+        for m in self.weight_matrices:
+            for name in _PACKED_NAMES:
+                del m._parameters[name]
+        self._packed = True
+        self._bind_sub_matrices()
+        return self
+
+    def _bind_sub_matrices(self):
+        import weakref
+        ref = weakref.ref(self)
+        for j, m in enumerate(self.weight_matrices):
+            object.__setattr__(m, "_packed_parent", ref)
+            object.__setattr__(m, "_index", j)
+            m.__class__ = _PackedSubMatrix
+
+    def __setstate__(self, state):             # unpickling and copy.deepcopy: point the sub-matrix views at THIS object
+        super().__setstate__(state)
+        if getattr(self, "_packed", False):
+            self._bind_sub_matrices()
+
+    def _stacked(self, name):
+        """(stack, D_in) tensor of one per-sub-matrix vector: the packed parameter itself, or a stack of the leaves."""
+        if self._packed:
+            return getattr(self, "packed_" + name)
+        return torch.stack([getattr(m, name) for m in self.weight_matrices])
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        if not self._packed:
+            return super()._save_to_state_dict(destination, prefix, keep_vars)
+        if self.bias is not None:
+            destination[prefix + "bias"] = self.bias if keep_vars else self.bias.detach()
+        for j in range(self.stack):                       # the reference's keys, sub-matrix by sub-matrix
+            for name in _PACKED_NAMES:
+                row = getattr(self, "packed_" + name)[j]
+                destination[f"{prefix}weight_matrices.{j}.{name}"] = row if keep_vars else row.detach()
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        if not self._packed:
+            return super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys,
+                                                 unexpected_keys, error_msgs)
+        for j in range(self.stack):
+            for name in _PACKED_NAMES:
+                key = f"{prefix}weight_matrices.{j}.{name}"
+                if key not in state_dict:
+                    missing_keys.append(key)
+                    continue
+                value = state_dict.pop(key)               # consumed here: the (parameter-less) sub-modules never see it
+                target = getattr(self, "packed_" + name)
+                if tuple(value.shape) != tuple(target.shape[1:]):
+                    error_msgs.append(f"size mismatch for {key}: {tuple(value.shape)} vs {tuple(target.shape[1:])}")
+                    continue
+                with torch.no_grad():
+                    target[j].copy_(value)
+        packed = {n: self._parameters.pop("packed_" + n) for n in _PACKED_NAMES}    # keep the base class off them
+        try:
+            super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                                          error_msgs)
+        finally:
+            for n, p_ in packed.items():
+                self._parameters["packed_" + n] = p_
 
     @staticmethod
     def setup_dimensions(D_in, D_out):
@@ -355,8 +454,8 @@ class WHVIStackedMatrix(nn.Module):
         if self._on_gpu():
             # one evaluation over all sub-matrices (they share lambda): the same sum of terms as the reference's
             # per-matrix loop, in one pass instead of stack x ~12 tiny launches
-            g_mu = torch.stack([m.g_mu for m in self.weight_matrices]).reshape(-1)
-            g_sigma = F.softplus(torch.stack([m.g_rho for m in self.weight_matrices])).reshape(-1)
+            g_mu = self._stacked("g_mu").reshape(-1)
+            g_sigma = F.softplus(self._stacked("g_rho")).reshape(-1)
             return kl_diag_normal(g_mu, g_sigma, torch.zeros_like(g_mu), torch.ones_like(g_mu) * self.lambda_)
         return sum(weight.kl for weight in self.weight_matrices)
 
@@ -364,18 +463,19 @@ class WHVIStackedMatrix(nn.Module):
         """All sub-matrices in ONE fused launch (the reference loops over them,
         src/weights.py:177-180: 4 FWHT launches each).  ``parts(m, eps)`` returns the list of ``u``
         vectors of sub-matrix m; result (stack, len(parts), D, D)."""
-        dev = self.weight_matrices[0].g_mu.device
+        dev = self._stacked_device()
         # one draw for every sub-matrix, in sub-matrix order like the reference's sequential draws
         eps = torch.randn(self.stack, self.D_in, device=dev)
-        s1 = torch.stack([m.s1 for m in self.weight_matrices])
-        s2 = torch.stack([m.s2 for m in self.weight_matrices])
-        g_mu = torch.stack([m.g_mu for m in self.weight_matrices])
-        g_sigma = F.softplus(torch.stack([m.g_rho for m in self.weight_matrices]))
+        s1, s2, g_mu = self._stacked("s1"), self._stacked("s2"), self._stacked("g_mu")
+        g_sigma = F.softplus(self._stacked("g_rho"))
         u = torch.stack(parts(g_mu, g_sigma, eps), dim=1)          # (stack, n_parts, D)
         return WBarFunction.apply(s1, u, s2, None, mean_plus)
 
+    def _stacked_device(self):
+        return (self.packed_g_mu if self._packed else self.weight_matrices[0].g_mu).device
+
     def _on_gpu(self):
-        return self.weight_matrices[0].g_mu.device.type == "cuda"
+        return self._stacked_device().type == "cuda"
 
     def sample(self):
         if self._on_gpu():
@@ -395,11 +495,9 @@ class WHVIStackedMatrix(nn.Module):
         (n_samples, batch, n_in) -> (n_samples, batch, n_out).  Sample k of sub-matrix j uses row
         ``[j, k]`` of one ``randn(stack, n_samples, D_in)`` draw."""
         S, J, D = n_samples, self.stack, self.D_in
-        dev = self.weight_matrices[0].g_mu.device
-        s1 = torch.stack([m.s1 for m in self.weight_matrices])
-        s2 = torch.stack([m.s2 for m in self.weight_matrices])
-        g_mu = torch.stack([m.g_mu for m in self.weight_matrices])
-        g_rho = torch.stack([m.g_rho for m in self.weight_matrices])
+        dev = self._stacked_device()
+        s1, s2 = self._stacked("s1"), self._stacked("s2")
+        g_mu, g_rho = self._stacked("g_mu"), self._stacked("g_rho")
         u, kl = _draw_and_reparam(self, g_mu, g_rho, S, self.lambda_)               # (J, 1 + S, D)
         self._mc_kl = None if kl is None else kl.sum()
         if dev.type == "cuda":
