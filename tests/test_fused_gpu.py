@@ -659,3 +659,46 @@ def test_packed_stacked_layer_on_gpu(monkeypatch, hip_lib):
             want = torch.stack([getattr(m, name).grad for m in plain.weight_submodule.weight_matrices])
             got = getattr(sub, "packed_" + name).grad
             assert float((got - want).abs().max()) <= 1e-6 * float(want.abs().max()), (use_mc, name)
+
+
+def test_network_and_likelihood_vs_reference_on_gpu(monkeypatch, hip_lib):
+    """The reference's recorded WHVIRegression run (tests/golden/network_golden.npz: predictions, MNLL, KL for replayed
+    eps) and its likelihood unit tests (test/likelihoods.py:8-56) with the network on the GPU: fused weight kernels,
+    one-launch Gaussian MNLL reduction.  1e-5 relative."""
+    import os
+    import torch.nn as nn
+    from whvi_amd.likelihoods import GaussianLikelihood
+    from whvi_amd.networks import WHVIRegression
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "network_golden.npz"))
+    net = WHVIRegression([nn.Linear(1, 8), nn.ReLU(), WHVILinear(8, 8), nn.ReLU(), nn.Linear(8, 2)],
+                         train_samples=3, eval_samples=4)
+    net.load_state_dict({k[len("state."):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("state.")})
+    net = net.to(DEV).train()
+    net.mc_mode = "loop"                      # the reference's RNG order: one draw per sample
+    monkeypatch.setattr(torch, "randn", ReplayRandn([g[f"eps{i}"] for i in range(int(g["n_eps"]))]))
+    pred = net(torch.from_numpy(g["x"]).to(DEV))
+    monkeypatch.undo()
+    want = torch.from_numpy(g["pred"])
+    assert float((pred.cpu() - want).abs().max()) <= 1e-5 * float(want.abs().max())
+    mnll = net.likelihood.mnll_batch_estimate(torch.from_numpy(g["y"]).to(DEV), pred, 100)
+    assert abs(float(mnll) - float(g["mnll"])) <= 1e-5 * abs(float(g["mnll"]))
+    assert abs(float(net.kl) - float(g["kl"])) <= 1e-5 * abs(float(g["kl"]))
+    mnll.backward()
+    assert net.likelihood.sigma.grad is not None and torch.isfinite(net.likelihood.sigma.grad)
+    # test/likelihoods.py: the explicit double loop, delta 1e-4
+    y = torch.reshape(torch.tensor([0., 1., 2., -1.]), (-1, 1)).to(DEV)
+    y_hat = torch.tensor([[0.2, 1.1, 2.2, -1.3], [-0.1, 1.05, 2, -1.1]]).T.unsqueeze(1).to(DEV)
+    got = float(GaussianLikelihood(sigma=1.0).to(DEV).mnll_batch_estimate(y, y_hat, 12))
+    assert abs(got - float(g["lik_value"])) < 1e-4
+    n, m, n_mc, sigma = 116, 24, 80, 15.21
+    gen = torch.Generator().manual_seed(1)
+    y, y_hat = torch.randn((m, 1), generator=gen), torch.randn((m, 1, n_mc), generator=gen)
+    target = 0.0
+    for j in range(m):
+        tmp = 0.0
+        for i in range(n_mc):
+            tmp += -(np.log(1 / (np.sqrt(2 * np.pi) * sigma)) - 0.5 * (float(y[j] - y_hat[j, 0, i]) / sigma) ** 2)
+        target += tmp / n_mc
+    target *= n / m
+    got = float(GaussianLikelihood(sigma=sigma).to(DEV).mnll_batch_estimate(y.to(DEV), y_hat.to(DEV), n))
+    assert abs(target - got) < 1e-4 * max(1.0, abs(target))
