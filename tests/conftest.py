@@ -17,6 +17,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """A fresh checkout has no binaries (they are git-ignored): build the HIP library (cross-compiles without a
+    GPU), the host library and the C oracle once, exactly as ``__graft_entry__.build()`` does."""
+    needed = [os.path.join(ROOT, "whvi_amd", "libwhvi_hip.so"), os.path.join(ROOT, "whvi_amd", "libwhvi_cpu.so")]
+    if all(os.path.exists(p) for p in needed):
+        return
+    import __graft_entry__
+    __graft_entry__.build()
+
+
 def pytest_collection_modifyitems(config, items):
     import torch
     if torch.cuda.is_available():
