@@ -25,6 +25,18 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 
 
+def bind_reference_src(reference):
+    """Make ``import src.*`` resolve to the REFERENCE tree only.  The reference's ``src`` has no ``__init__.py``
+    (a namespace package), so this repo's ``src/`` alias package -- a regular package -- would win the import no
+    matter where it sits on sys.path; pin the package object by hand and check where the modules come from."""
+    import types
+    pkg = types.ModuleType("src")
+    pkg.__path__ = [os.path.join(reference, "src")]
+    sys.modules["src"] = pkg
+    import src.layers
+    assert os.path.abspath(src.layers.__file__).startswith(os.path.abspath(reference) + os.sep), src.layers.__file__
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default="/root/reference")
@@ -37,6 +49,7 @@ def main():
     import torch
     import fwht_cpp  # the reference's compiled module
     assert os.path.dirname(fwht_cpp.__file__) == ref_so_dir, fwht_cpp.__file__
+    bind_reference_src(args.reference)
     import src.fwht.cpp.fwht as ref_cpp
     import src.fwht.python.fwht as ref_py
     from src.utils import build_H, kl_diag_normal, matmul_diag_left, matmul_diag_right
