@@ -154,15 +154,62 @@ def event_ms(fn, iters=10, warm=2):
     return e0.elapsed_time(e1) / iters
 
 
-def recorded_traffic(workload_key):
-    """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (collected and
-    corrected as MI355X_MICROARCH.md prescribes: separate --pmc passes, FETCH_SIZE doubled)."""
+KERNEL_SOURCES = ("whvi_amd/csrc/kernels.hpp", "whvi_amd/csrc/fwht_tile.hpp", "whvi_amd/csrc/dispatch.hpp",
+                  "whvi_amd/csrc/Makefile")
+
+
+def kernel_source_hash():
+    """sha256 over the kernel sources + build flags: ties a PMC record under profiles/ to the build it was taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def event_ms_each(fn, between, iters=10, warm=2):
+    """Average ms of ``fn`` alone when every call is followed by ``between(i)`` (untimed housekeeping on the stream):
+    one HIP-event pair per call."""
+    for i in range(warm):
+        fn()
+        between(i)
+    torch.cuda.synchronize()
+    pairs = []
+    for i in range(iters):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        between(i)
+        pairs.append((e0, e1))
+    torch.cuda.synchronize()
+    return sum(a.elapsed_time(b) for a, b in pairs) / iters
+
+
+def _finite(t):
+    """Cheap finiteness probe of a large buffer after a timed run: every 4099th row (plus the last)."""
+    rows = t.reshape(-1, t.shape[-1])
+    return bool(torch.isfinite(rows[::4099].float()).all()) and bool(torch.isfinite(rows[-1].float()).all())
+
+
+def recorded_traffic(workload_key, kernel_symbol):
+    """(HBM bytes per launch, note) from the rocprofv3 PMC passes committed under profiles/ (collected and corrected as
+    MI355X_MICROARCH.md prescribes: separate --pmc passes, FETCH_SIZE doubled; tools/update_hbm_traffic.py).  The
+    record carries the kernel symbol it was measured on and a hash of the kernel sources; when either differs from
+    what this run launched the counters say nothing about this build and ``traffic`` is null."""
     path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     try:
         rec = json.load(open(path)).get(workload_key)
-        return rec["hbm_bytes_per_launch"] if rec else None
-    except (OSError, ValueError, KeyError):
-        return None
+    except (OSError, ValueError):
+        rec = None
+    if not rec:
+        return None, f"no PMC record for {workload_key} in profiles/hbm_traffic.json"
+    if rec.get("kernel_symbol") != kernel_symbol:
+        return None, f"PMC record is for {rec.get('kernel_symbol')!r}, this run launched {kernel_symbol!r}"
+    if rec.get("source_sha256") != kernel_source_hash():
+        return None, "kernel sources changed since the PMC passes in profiles/hbm_traffic.json: re-collect them"
+    return rec["hbm_bytes_per_launch"], f"PMC passes of this build: {rec.get('source', 'profiles/')}"
 
 
 def cpu_baseline(log2d, target_s=25.0):
@@ -242,6 +289,7 @@ def _extra_sweep(device):
         rows = (1 << 32) // (4 * d)
         x = torch.randn(rows, d, device=device) * 2.0 ** -64
         out[f"D={d}"] = _rate(rows, d, 4, event_ms(lambda: _hip.fwht_rows(x, out=x), iters=10, warm=10))
+        out[f"D={d}"].update(kernel=_hip.last_kernel(), values_finite=_finite(x))
         del x
     return out
 
@@ -250,7 +298,13 @@ def _extra_f16(device):
     """BASELINE config 5 (one GPU's share): D = 4096 fp16, 2^20 rows = 8 GiB."""
     from whvi_amd import _hip
     x = (torch.randn(1 << 20, 4096, device=device) * 2.0 ** -8).half()
-    return _rate(1 << 20, 4096, 2, event_ms(lambda: _hip.fwht_rows(x, out=x), iters=10, warm=10))
+    # two in-place transforms multiply the data by 4096, which fp16 (max 65504) survives once: every second launch is
+    # followed by an exact 2^-12 rescale, and each transform is timed by its own event pair so the rescale is in
+    # neither the count nor the time
+    res = _rate(1 << 20, 4096, 2, event_ms_each(lambda: _hip.fwht_rows(x, out=x), lambda i: x.mul_(2.0 ** -12) if i & 1 else None,
+                                                iters=10, warm=10))
+    res.update(kernel=_hip.last_kernel(), values_finite=_finite(x))
+    return res
 
 
 def _extra_fused(device):
@@ -258,10 +312,14 @@ def _extra_fused(device):
     from whvi_amd import _hip
     d, S, B = 2048, 64, 8192
     x = torch.randn(B * S, d, device=device)
-    a, c = torch.randn(d, device=device) * 0.01, torch.randn(d, device=device) * 0.01
+    # S1, S2 = random signs scaled by D^-1/2 (the sign-flip matrices of the WHVI parameterisation) and g ~ N(0, 1): one
+    # launch then preserves the data's norm in expectation, so 50 in-place launches stay in range
+    a = (torch.randint(0, 2, (d,), device=device).float() * 2 - 1) * d ** -0.5
+    c = (torch.randint(0, 2, (d,), device=device).float() * 2 - 1) * d ** -0.5
     g = torch.randn(S, d, device=device)
     ms = event_ms(lambda: _hip.fused_shs(x, a, g, c, axis="col", n_samples=S, sample_stride=1, out=x), iters=20, warm=30)   # clocks take ~25 launches to ramp
     res = _rate(B * S, d, 4, ms)
+    res.update(kernel=_hip.last_kernel(), values_finite=_finite(x), max_abs_after_50_launches=float(x[::4099].abs().max()))
     res["note"] = ("one fused launch = 2 FWHTs + 3 scalings per row; unfused (2 FWHT launches + 3 elementwise) "
                    "moves 5x the bytes")
     return res
@@ -289,7 +347,9 @@ def _extra_layer(device):
         (layer.forward_mc(h, 32).square().mean() + layer.kl).backward()
     ms_loop, ms_batched = event_ms(loop, iters=5, warm=2), event_ms(batched, iters=5, warm=2)
     ms_train = event_ms(train, iters=5, warm=2)
-    return {"loop_ms": round(ms_loop, 3), "loop_ms_per_mc_sample": round(ms_loop / 32, 4),
+    with torch.no_grad():
+        finite = _finite(layer.forward_mc(h, 32)) and all(bool(torch.isfinite(p.grad).all()) for p in layer.parameters())
+    return {"values_finite": finite, "loop_ms": round(ms_loop, 3), "loop_ms_per_mc_sample": round(ms_loop / 32, 4),
             "batched_ms": round(ms_batched, 3), "batched_ms_per_mc_sample": round(ms_batched / 32, 4),
             "batched_fwd_kl_bwd_ms": round(ms_train, 3),
             "modes": "loop = the reference's one forward per MC sample; batched = forward_mc "
@@ -314,6 +374,7 @@ def _extra_network(device):
             with torch.no_grad():
                 return net(xb)
         res[mode + "_ms"] = round(event_ms(predict, iters=3, warm=1), 3)
+        res["values_finite"] = res.get("values_finite", True) and bool(torch.isfinite(predict()).all())
     # opt-in shortcut (default off): the as-written square weight is exactly D * diag(s1 * u * s2), so the layer can
     # skip weight construction and GEMM with bit-identical outputs (tests/test_fused_gpu.py)
     net.mc_mode = "batched"
@@ -352,15 +413,18 @@ def _extra_toy(device):
         train_step()
     torch.cuda.synchronize()
     rate = round(100 / (time.perf_counter() - t0), 1)
-    # the same step replayed from a hipGraph (loss + backward + Adam in one launch): measured in a child process
-    # on a fresh network -- capturing a network that already ran eager backward passes on the default stream
-    # can abort inside the HIP runtime, and an optional number must never cost the bench line
+    # the same step replayed from a hipGraph (loss + backward + Adam in one launch), as a child process with its exit
+    # code in the line: a failure of this optional number shows up here instead of costing the bench line.  (The
+    # process abort of early round 1 -- capture with a stale autograd graph alive -- is a RuntimeError now:
+    # whvi_amd/graphs.py, tests/test_fused_gpu.py::test_graphed_train_step_rejects_a_stale_autograd_graph.)
     import subprocess
+    child_exit = None
     try:
         child = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "toy_graph_train.py")],
                                capture_output=True, text=True, timeout=180)
+        child_exit = child.returncode
         line = [ln for ln in child.stdout.splitlines() if ln.startswith("{")]
-        graph_rate = json.loads(line[-1])["it_per_s"] if line else f"failed (exit {child.returncode})"
+        graph_rate = json.loads(line[-1])["it_per_s"] if line else f"failed: {child.stderr.strip().splitlines()[-1:]}"
     except Exception as err:
         graph_rate = f"failed ({err!r})"
     toy.eval()
@@ -372,7 +436,7 @@ def _extra_toy(device):
     gp = GraphedPredictor(toy, tx, 64)
     graph_ms = event_ms(lambda: gp(tx), iters=200, warm=5)
     return {"training_it_per_s_with_kl": rate, "training_it_per_s_with_kl_hipgraph": graph_rate,
-            "reference_published_it_per_s_with_kl": 153.17,
+            "hipgraph_child_exit_code": child_exit, "reference_published_it_per_s_with_kl": 153.17,
             "predict_64mc_eager_ms": round(eager_ms, 4), "predict_64mc_hipgraph_replay_ms": round(graph_ms, 4),
             "note": "eager training loop is launch-bound; the reference number is from its notebook on an "
                     "unspecified CUDA GPU"}
@@ -413,19 +477,21 @@ def _timed_all_ranks(fn, iters, device):
     return float(t.item())
 
 
-def multi_gpu_extras(device, rank, world):
+def multi_gpu_extras(device, rank, world, small=False):
     """N > 1 only, every rank takes part: BASELINE config 5 (D = 4096 fp16, 2^20 rows in total, row-sharded: the
     strong-scaling curve) and config 4 (WHVIRegression 3 -> 1024 -> 1024 -> 1, 128 MC samples sharded over the
     ranks, ONE RCCL all-gather of the predictions per forward).  Ranks vote before each phase, so a local failure
-    skips the phase everywhere instead of leaving the others inside a collective."""
+    skips the phase everywhere instead of leaving the others inside a collective.  ``small``: the same code path at
+    test sizes (tests/test_rccl_gpu.py drives it through a one-rank RCCL group)."""
     out = {}
     gpu = device.type == "cuda"
+    rows_total = (1 << 12) if small else (1 << 20)
     # ---- config 5
     x16, err = None, None
     try:
         if gpu:
             from whvi_amd import _hip
-            rows = (1 << 20) // world
+            rows = rows_total // world
             x16 = (torch.randn(rows, 4096, device=device) * 2.0 ** -8).half()
     except Exception as e:                      # noqa: BLE001
         err = repr(e)
@@ -449,7 +515,7 @@ def multi_gpu_extras(device, rank, world):
         from whvi_amd.layers import WHVILinear
         from whvi_amd.networks import WHVIRegression
         from whvi_amd.parallel import mc_sharded_forward
-        width, batch, n_mc = (1024, 45730, 128) if gpu else (8, 16, 4)
+        width, batch, n_mc = (1024, 45730, 128) if gpu and not small else ((64, 33, 8) if gpu else (8, 16, 4))
         torch.manual_seed(4)                    # replicated parameters: same seed on every rank
         net = WHVIRegression([WHVILinear(3, width), nn.ReLU(), WHVILinear(width, width), nn.ReLU(),
                               WHVILinear(width, 1)], eval_samples=n_mc).to(device).eval()
@@ -491,6 +557,11 @@ def main():
 
     wall, ev_ms = timed(step, args.steps, args.warmup, device, world)
     finite = bool(torch.isfinite(x[:: max(1, rows // 64)]).all())
+    if device.type == "cuda":
+        kernel_symbol = _hip.last_kernel()       # what the library's dispatch actually launched for this shape
+        traffic, traffic_note = recorded_traffic(f"fwht_f32_D{d}_rows{rows}", kernel_symbol)
+    else:
+        kernel_symbol, traffic, traffic_note = "host library (CPU plumbing mode)", None, "no GPU"
     value = world * rows * args.steps / wall / 1e9
     alg_bytes = rows * 2 * d * 4                      # per launch: read once + write once
     achieved = alg_bytes / (ev_ms * 1e-3) / 1e9
@@ -506,8 +577,7 @@ def main():
                    "values_finite_after_run": finite},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4),
-                     "traffic": recorded_traffic(f"fwht_f32_D{d}_rows{rows}"),
-                     "kernel": "whvi::fwht_rows_kernel<float,12,16,DPP,one-tile-per-wave,nontemporal,256,store-barrier>",
+                     "traffic": traffic, "traffic_note": traffic_note, "kernel": kernel_symbol,
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms_hip_events": round(ev_ms, 4)},
     }
     if rank == 0 and world == 1 and not CPU_PLUMBING:
@@ -530,6 +600,12 @@ def main():
         multi = multi_gpu_extras(device, rank, world)
         if rank == 0:
             rec["extras_multi_gpu"] = multi
+    if world > 1 and rank == 0:
+        # what the collectives actually ran on: the backend torch.distributed reports ("nccl" is RCCL on ROCm)
+        rec["distributed"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                              "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version())
+                              if device.type == "cuda" else None,
+                              "launcher": "torch.distributed.run (env://), one process per GPU"}
     if rank == 0:
         print(json.dumps(rec), flush=True)
     if world > 1:

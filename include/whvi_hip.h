@@ -61,6 +61,13 @@ extern "C" {
 
 int         whvi_hip_abi_version(void);
 const char *whvi_last_error(void);          /* thread-local; "" when the last call succeeded */
+int         whvi_last_kernel(char *buf, int32_t size);
+                                            /* writes the demangled symbol of the kernel instantiation the calling
+                                             * thread's last FWHT / fused launch selected (the name rocprofv3 prints,
+                                             * e.g. "whvi::fwht_rows_kernel<float, 12, 16, 0, false, true, 256, 1>");
+                                             * returns its length, 0 before any launch.  Measurement aid: the
+                                             * reference has no counterpart (its launcher picks between two kernels
+                                             * silently, fwht_cuda_kernel.cu:156-181)                          */
 int         whvi_max_log2d(int32_t dtype);  /* largest supported log2(D): 24 for f32/f64/i32 (rows beyond
                                              * 8192 / 4096 elements take extra high-bit passes), 13 for
                                              * f16/bf16 (single pass only: one rounding)              */

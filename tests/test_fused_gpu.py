@@ -346,6 +346,60 @@ def test_graphed_train_step_learns(hip_lib):
     assert rmse < 0.5
 
 
+def test_graphed_train_step_rejects_a_stale_autograd_graph(hip_lib):
+    """A `loss` of an earlier eager pass kept alive (here: a list of losses) leaves the parameters' gradient
+    accumulators on the default stream; capturing a backward pass through them aborts inside the HIP runtime.
+    GraphedTrainStep must notice during its warm-up and raise -- and work once the tensors are dropped."""
+    import torch.nn as nn
+    from whvi_amd.graphs import GraphedTrainStep
+    from whvi_amd.networks import WHVIRegression
+    torch.manual_seed(0)
+    net = WHVIRegression([nn.Linear(1, 32), nn.Tanh(), WHVILinear(32, 32, lambda_=1.0), nn.Tanh(), nn.Linear(32, 1)],
+                         train_samples=2).to(DEV).train()
+    x = torch.linspace(-1, 1, 64, device=DEV).unsqueeze(1)
+    y = torch.sin(3 * x)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-2, capturable=True)
+    kept = []
+    for _ in range(2):
+        opt.zero_grad(set_to_none=False)
+        loss = net.loss(x, y, n=64)
+        loss.backward(retain_graph=True)
+        kept.append(loss)
+        opt.step()
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="autograd graph of an earlier pass is still alive"):
+        GraphedTrainStep(net, opt, x, y, n=64)
+    kept.clear()
+    del loss
+    step = GraphedTrainStep(net, opt, x, y, n=64)
+    assert torch.isfinite(step(x, y))
+
+
+def test_reparam_kl_double_backward_vs_torch_ops(hip_lib):
+    """Second derivatives through ReparamKLFunction (a gradient penalty on g_rho / g_mu): the create_graph branch must
+    differentiate through sigma = softplus(g_rho) -- in 1 / sigma of the KL term and in grad_eps = grad_u * sigma."""
+    from whvi_amd.weights import ReparamKLFunction
+    J, S, D, lam = 2, 3, 40, 0.7
+    g = torch.Generator().manual_seed(5)
+    mu0, rho0 = torch.randn(J, D, generator=g) * 0.3, torch.rand(J, D, generator=g) - 3
+    eps0, w = torch.randn(J, S, D, generator=g), torch.randn(J, S + 1, D, generator=g).to(DEV)
+
+    def penalty(use_kernel):
+        mu, rho, eps = (t.clone().to(DEV).requires_grad_(True) for t in (mu0, rho0, eps0))
+        if use_kernel:
+            u, kl = ReparamKLFunction.apply(mu, rho, eps, lam)
+        else:
+            sigma = torch.nn.functional.softplus(rho)
+            u = torch.cat((mu.unsqueeze(1), sigma.unsqueeze(1) * eps), dim=1)
+            kl = 0.5 * (math.log(lam) * D - torch.log(sigma).sum(1) - D + (sigma / lam).sum(1) + (mu * (mu / lam)).sum(1))
+        loss = (u * w).sum() + (u.square() * w).sum() + 3.0 * kl.sum()
+        g_mu, g_rho, g_eps = torch.autograd.grad(loss, (mu, rho, eps), create_graph=True)
+        (g_mu.square().sum() + g_rho.square().sum() + g_eps.square().sum()).backward()
+        return [t.grad.detach().cpu() for t in (mu, rho, eps)]
+    for got, want, name in zip(penalty(True), penalty(False), ("mu", "rho", "eps")):
+        assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max()), name
+
+
 @pytest.mark.parametrize("dtype,J,S,D,R", [
     (torch.float32, 1, 1, 4, 4), (torch.float32, 1, 3, 8, 8), (torch.float32, 2, 2, 64, 64), (torch.float32, 3, 2, 16, 5),
     (torch.float32, 1, 2, 256, 256), (torch.float32, 2, 3, 512, 512), (torch.float32, 1, 2, 1024, 1000),

@@ -77,6 +77,34 @@ def _worker(rank, world, port, tmp):
         both = [torch.zeros_like(before) for _ in range(world)]
         dist.all_gather(both, before)
         assert torch.allclose(after, sum(both) / world, rtol=1e-6, atol=1e-7)
+
+        # 4. a rank with missing gradients sends zeros in the same layout (never a shorter buffer, never a skip)
+        for p in net.parameters():
+            p.grad = None
+        if rank == 0:
+            net.loss(x, y, n=60).backward()
+            mine = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).clone()
+        parallel.all_reduce_grads(net)
+        after = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+        ref = mine if rank == 0 else torch.zeros_like(after)
+        dist.broadcast(ref, src=0)
+        assert torch.allclose(after, ref / world, rtol=1e-6, atol=1e-7)
+
+        # 5. the opt-in in-kernel Philox stream is seeded per rank (ranks share torch.manual_seed for their parameters)
+        torch.manual_seed(7)
+        from whvi_amd.weights import _fresh_philox_seed
+        seeds = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(seeds, torch.tensor([_fresh_philox_seed()], dtype=torch.int64))
+        assert len({int(t) for t in seeds}) == world, "same torch seed, different ranks -> different Philox seeds"
+        wnet = WHVIRegression([WHVILinear(3, 8), nn.ReLU(), WHVILinear(8, 8), nn.ReLU(), WHVILinear(8, 1)])
+        wnet.set_inkernel_rng()
+        n_rng = sum(1 for m in wnet.modules() if getattr(m, "inkernel_rng", False))    # weight modules + their squares
+        assert n_rng >= 3 and parallel.seed_inkernel_rng(wnet, base_seed=5) == n_rng
+        mine = torch.stack([m._rng_state for m in wnet.modules() if getattr(m, "_rng_state", None) is not None])
+        assert mine.shape == (n_rng, 3) and len({int(v) for v in mine[:, 0]}) == n_rng and int(mine[:, 1].abs().sum()) == 0
+        states = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(states, mine)
+        assert len({int(v) for st in states for v in st[:, 0]}) == n_rng * world, "every (rank, layer) has its own seed"
         open(os.path.join(tmp, f"ok{rank}"), "w").write("ok")
     finally:
         dist.destroy_process_group()
@@ -107,3 +135,5 @@ def test_bench_two_ranks_gloo_cpu_plumbing(tmp_path):
     # the N > 1 extras: MC-sharded network pass with one all-gather (tiny sizes in plumbing mode)
     sharded = rec["extras_multi_gpu"]["whviregression_3_1024_1024_1_mc128_sharded"]
     assert sharded["prediction_shape"] == [16, 1, 4] and sharded["mc_samples_per_gpu"] == 2 and sharded["ms"] > 0
+    # the line says which backend and how many ranks the collectives saw
+    assert rec["distributed"]["backend"] == "gloo" and rec["distributed"]["world_size"] == 2

@@ -39,5 +39,6 @@ torch.cuda.synchronize()
 eager = N / (time.perf_counter() - t0)
 print(f"eager: {eager:.1f} it/s (with KL)", flush=True)
 
-# hipGraph capture of the whole step (torch.cuda.graph around loss/backward/Adam) crashed the process on
-# ROCm 7.0 torch + ctypes launches from the autograd thread when tried in round 1; not pursued.
+# The same step replayed from a hipGraph: tools/toy_graph_train.py (whvi_amd.graphs.GraphedTrainStep).  The process
+# abort seen early in round 1 was a stale autograd graph (a kept `loss`) whose gradient accumulators lived on the
+# default stream; GraphedTrainStep now detects that during its warm-up and raises RuntimeError instead.

@@ -42,6 +42,8 @@ def _declare(lib):
     lib.whvi_last_error.argtypes = []
     lib.whvi_max_log2d.restype = ctypes.c_int
     lib.whvi_max_log2d.argtypes = [i32]
+    lib.whvi_last_kernel.restype = ctypes.c_int
+    lib.whvi_last_kernel.argtypes = [ctypes.c_char_p, i32]
     for sfx in ("f32", "f64", "f16", "bf16", "i32"):
         fn = getattr(lib, "whvi_fwht_" + sfx)
         fn.restype = ctypes.c_int
@@ -109,6 +111,13 @@ def is_built() -> bool:
 
 def last_error() -> str:
     return lib().whvi_last_error().decode()
+
+
+def last_kernel() -> str:
+    """Demangled symbol of the kernel instantiation this thread's last FWHT / fused launch selected ("" before any)."""
+    buf = ctypes.create_string_buffer(256)
+    lib().whvi_last_kernel(buf, 256)
+    return buf.value.decode()
 
 
 def max_log2d(dtype: torch.dtype) -> int:

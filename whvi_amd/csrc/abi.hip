@@ -21,14 +21,20 @@ int after_launch(const char *what)
     return WHVI_OK;
 }
 
-// CU count of the current device, per calling thread's device (cheap attribute query)
+thread_local LaunchNote g_note;
+
+// CU count of the calling thread's current device; the attribute query runs once per device, later calls cost one
+// hipGetDevice (a thread-local read) -- the launch-bound training steps make ~100 launches per step
 int num_cu()
 {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) == hipSuccess &&
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
-        return n;
-    return 256;
+    static int cached[64] = {0};       // written once per device with the same value: benign if two threads race
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cached[dev] == 0) {
+        int n = 0;
+        cached[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    return cached[dev];
 }
 
 }  // namespace whvi
@@ -37,6 +43,18 @@ using namespace whvi;
 
 extern "C" __attribute__((visibility("default"))) int whvi_hip_abi_version(void) { return WHVI_HIP_ABI_VERSION; }
 extern "C" __attribute__((visibility("default"))) const char *whvi_last_error(void) { return g_err; }
+
+extern "C" __attribute__((visibility("default"))) int whvi_last_kernel(char *buf, int32_t size)
+{
+    if (buf == nullptr || size <= 0) return -1;
+    if (g_note.family == nullptr) { buf[0] = 0; return 0; }
+    int off = snprintf(buf, (size_t)size, "whvi::%s<%s", g_note.family, g_note.type);
+    for (int i = 0; i < g_note.n && off > 0 && off < size; ++i)
+        off += g_note.is_bool[i] ? snprintf(buf + off, (size_t)(size - off), ", %s", g_note.arg[i] ? "true" : "false")
+                                 : snprintf(buf + off, (size_t)(size - off), ", %d", g_note.arg[i]);
+    if (off > 0 && off < size) off += snprintf(buf + off, (size_t)(size - off), ">");
+    return off;
+}
 
 extern "C" __attribute__((visibility("default"))) int whvi_max_log2d(int32_t dtype)
 {

@@ -13,6 +13,41 @@ int fail(int code, const char *fmt, const char *a = "", long long x = 0, long lo
 int after_launch(const char *what);
 int num_cu();
 
+// Which kernel instantiation the calling thread's last launch selected -- the demangled symbol rocprofv3 prints,
+// formatted lazily by whvi_last_kernel() (abi.hip).  A few stores per launch; lets bench.py name the kernel it
+// actually timed instead of a literal.
+struct LaunchNote {
+    const char *family = nullptr;     // "fwht_rows_kernel", "fused_shs_kernel", ...
+    const char *type = nullptr;
+    int n = 0;                        // template arguments after the type
+    int arg[8] = {0};
+    unsigned char is_bool[8] = {0};
+};
+extern thread_local LaunchNote g_note;
+template <typename T> constexpr const char *type_name()
+{
+    if (std::is_same<T, float>::value) return "float";
+    if (std::is_same<T, double>::value) return "double";
+    if (std::is_same<T, int32_t>::value) return "int";
+    if (std::is_same<T, __half>::value) return "__half";
+    return "__hip_bfloat16";
+}
+struct NB { int v; bool b; };                       // template argument + "print as bool"
+inline NB nb(int v) { return NB{v, false}; }
+inline NB nb(bool v) { return NB{v ? 1 : 0, true}; }
+template <typename T, typename... A>
+inline void note_launch(const char *family, A... a)
+{
+    const NB args[] = {nb(a)...};
+    g_note.family = family;
+    g_note.type = type_name<T>();
+    g_note.n = (int)sizeof...(A);
+    for (int i = 0; i < (int)sizeof...(A) && i < 8; ++i) {
+        g_note.arg[i] = args[i].v;
+        g_note.is_bool[i] = args[i].b;
+    }
+}
+
 // MC samples one block of the reparameterisation kernels covers (abi.hip, train_aux.hip)
 constexpr int REPARAM_SAMPLES_PER_BLOCK = 8;
 
@@ -110,6 +145,7 @@ inline void launch_rows(void *dst, const void *src, int64_t n_chunks, int varian
         int64_t grid = (n_tiles + (BLK / 64) - 1) / (BLK / 64);                                        \
         if (bpc > 0 && grid > (int64_t)num_cu() * bpc) grid = (int64_t)num_cu() * bpc;                 \
         const size_t smem = (POL == POLICY_LDS) ? (size_t)(BLK / 64) * rows_slab_bytes : 0;          \
+        note_launch<T>("fwht_rows_kernel", LOG2D, K, (int)POL, (bool)PF, (bool)NT, (int)BLK, 0);       \
         hipLaunchKernelGGL((fwht_rows_kernel<T, LOG2D, K, POL, PF, NT, BLK>), dim3((unsigned)grid),    \
                            dim3(BLK), smem, st, d, s, n_chunks, n_tiles);                              \
     } while (0)
@@ -130,12 +166,17 @@ inline void launch_rows(void *dst, const void *src, int64_t n_chunks, int varian
                     // 16-bit storage: half the bytes per butterfly, so the DPP network's VALU time co-limits the
                     // stream (6.1 TB/s).  The LDS-staged network needs a third of the issue slots: fp16 6.4,
                     // bf16 6.5 TB/s (tools/probe_f16.py), even at 8 waves per CU (16.6 KB of LDS per wave).
+                {
+                    note_launch<T>("fwht_rows_kernel", LOG2D, K, POLICY_LDS, false, true, 256, 1);
                     hipLaunchKernelGGL((fwht_rows_kernel<T, LOG2D, K, POLICY_LDS, false, true, 256, 1>),
                                        dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), (size_t)4 * rows_slab_bytes, st,
                                        d, s, n_chunks, n_tiles);
-                else
+                }
+                else {
+                    note_launch<T>("fwht_rows_kernel", LOG2D, K, POLICY_DPP, false, true, 256, 1);
                     hipLaunchKernelGGL((fwht_rows_kernel<T, LOG2D, K, POLICY_DPP, false, true, 256, 1>),
                                        dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, st, d, s, n_chunks, n_tiles);
+                }
             } else if (big && sizeof(T) == 8) WHVI_LAUNCH(POLICY_DPP, false, false, BIG);
             // cache-resident sizes: 256-thread blocks match or beat 1024 at every size (tools/probe_midsize.py:
             // 6.6-6.8 vs 6.5-6.7 TB/s at 128-256 MiB in place, 6.7 vs 5.3 at 32 MiB)
@@ -143,10 +184,11 @@ inline void launch_rows(void *dst, const void *src, int64_t n_chunks, int varian
         } else {
             // tiles of more than 64 data VGPRs (one row per wave: f32 D = 8192, f64 D = 4096): 256-thread blocks
             // either way; streams get the non-temporal accesses and the store barrier as well
-            if (big && nt)
+            if (big && nt) {
+                note_launch<T>("fwht_rows_kernel", LOG2D, K, POLICY_DPP, false, true, 256, 1);
                 hipLaunchKernelGGL((fwht_rows_kernel<T, LOG2D, K, POLICY_DPP, false, true, 256, 1>),
                                    dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, st, d, s, n_chunks, n_tiles);
-            else WHVI_LAUNCH(POLICY_DPP, false, false, 256);
+            } else WHVI_LAUNCH(POLICY_DPP, false, false, 256);
         }
         return;
     }
@@ -290,12 +332,15 @@ inline void launch_fused(void *dst, const void *src, const void *a, const void *
     const bool big = SMALL_TILE && n_tiles >= (int64_t)32 * num_cu();
     const bool nt = big && stream_sized(n_chunks * 16, dst, src);
 #define WHVI_FUSED(AX, EYE, NT, BLK, POL, STG)                                                          \
-    hipLaunchKernelGGL((fused_shs_kernel<T, LOG2D, K, AX, EYE, NT, BLK, POL, STG>),                     \
-                       dim3((unsigned)((n_tiles + (BLK / 64) - 1) / (BLK / 64))), dim3(BLK),            \
-                       ((POL == POLICY_LDS) ? (size_t)(BLK / 64) * slab_bytes : 0) +                    \
-                           ((STG) ? (size_t)8 << LOG2D : 0), st,                                        \
-                       (u32x4 *)dst, (const u32x4 *)src, (const T *)a, (const T *)b, (const T *)c,      \
-                       n_chunks, n_tiles, ds, dn, dg, flags)
+    do {                                                                                                \
+        note_launch<T>("fused_shs_kernel", LOG2D, K, (int)AX, (bool)EYE, (bool)NT, (int)BLK, (int)POL, (bool)STG); \
+        hipLaunchKernelGGL((fused_shs_kernel<T, LOG2D, K, AX, EYE, NT, BLK, POL, STG>),                 \
+                           dim3((unsigned)((n_tiles + (BLK / 64) - 1) / (BLK / 64))), dim3(BLK),        \
+                           ((POL == POLICY_LDS) ? (size_t)(BLK / 64) * slab_bytes : 0) +                \
+                               ((STG) ? (size_t)8 << LOG2D : 0), st,                                    \
+                           (u32x4 *)dst, (const u32x4 *)src, (const T *)a, (const T *)b, (const T *)c,  \
+                           n_chunks, n_tiles, ds, dn, dg, flags);                                       \
+    } while (0)
     constexpr bool LDS_OK = sizeof(typename Elem<T>::acc) == 4 && K * VEC == 64;
     constexpr size_t slab_bytes = (size_t)K * (64 * VEC + VEC) * 4;   // lds_slab_floats<VEC, K>() * 4
     // Column-axis launch of big problems, measured on MI355X (tools/tune_fused.py, D = 2048 / 4096,
@@ -305,7 +350,13 @@ inline void launch_fused(void *dst, const void *src, const void *a, const void *
     //   dpp/256/nt/staged 5.05 TB/s | lds/256 5.00 | dpp/256 4.70 | dpp/512/nt 4.04 | lds/512/nt 4.40
     //   (one 8 KiB row per wave at D = 2048 -- 106 VGPRs, twice the waves -- ties at 4.87; 1024-thread blocks 4.4)
     // WHVI_FUSED_TUNE=<policy 0|2><block 2|5 (unused: always 256)><nt 0|1><stage 0|1> overrides (read once).
-    static const char *tune_env = getenv("WHVI_FUSED_TUNE");
+    static const char *tune_env = [] {          // ignored unless it is exactly four digits: never read past the NUL
+        const char *e = getenv("WHVI_FUSED_TUNE");
+        if (e == nullptr || strlen(e) != 4) return (const char *)nullptr;
+        for (int i = 0; i < 4; ++i)
+            if (e[i] < '0' || e[i] > '9') return (const char *)nullptr;
+        return e;
+    }();
     const int t_pol = tune_env ? tune_env[0] - '0' : 0;
     const int t_nt = tune_env ? tune_env[2] - '0' : (nt ? 1 : 0);
     const int t_stg = tune_env ? tune_env[3] - '0' : 1;

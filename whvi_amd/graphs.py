@@ -11,6 +11,7 @@ fused weight kernel runs from the autograd engine's thread and is captured with 
 (tools/graph_train_probe.py walks through the stages).
 """
 import gc
+import warnings
 
 import torch
 
@@ -57,8 +58,10 @@ class GraphedTrainStep:
 
     It may be built after the network has trained eagerly, provided no tensor of an earlier pass that still carries
     an autograd graph (a kept ``loss``) is alive: gradient accumulators created by a backward pass on another
-    stream make the capture abort inside the HIP runtime (torch warns about an "AccumulateGrad node's stream"
-    mismatch first).  ``WHVINetwork.loss`` itself keeps only detached monitoring values."""
+    stream would make the capture abort the PROCESS inside the HIP runtime.  That precondition is checked: the
+    side-stream warm-up runs with torch's "AccumulateGrad node's stream does not match" warning promoted, and a
+    ``RuntimeError`` is raised before capture begins when it fires.  ``WHVINetwork.loss`` itself keeps only
+    detached monitoring values."""
 
     def __init__(self, net, optimizer, example_x, example_y, n: int, ignore_kl: bool = False, warmup: int = 3):
         if example_x.device.type != "cuda":
@@ -80,10 +83,32 @@ class GraphedTrainStep:
         torch.cuda.synchronize(dev)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
-            for _ in range(warmup):
-                self._eager_step()
+        # A stale autograd graph (a kept ``loss`` of an earlier eager pass) keeps the parameters' AccumulateGrad nodes
+        # alive on the stream that created them; the warm-up's backward on the side stream then has to synchronise
+        # with that stream -- harmless here, a process abort inside torch.cuda.graph.  torch warns about exactly that
+        # (once per process unless warn-always is on), so the warm-up doubles as the check.
+        warn_always = torch.is_warn_always_enabled()
+        torch.set_warn_always(True)
+        try:
+            with warnings.catch_warnings(record=True) as caught:
+                warnings.simplefilter("always")
+                with torch.cuda.stream(side):
+                    for _ in range(max(1, warmup)):
+                        self._eager_step()
+        finally:
+            torch.set_warn_always(warn_always)
         torch.cuda.current_stream(dev).wait_stream(side)
+        stale = [w for w in caught if "AccumulateGrad node's stream" in str(w.message)]
+        for w in caught:                             # everything else is passed on unchanged
+            if w not in stale:
+                warnings.warn_explicit(w.message, w.category, w.filename, w.lineno)
+        if stale:
+            optimizer.zero_grad(set_to_none=True)
+            raise RuntimeError(
+                "GraphedTrainStep: an autograd graph of an earlier pass is still alive (a kept `loss` tensor, a list of "
+                "losses, ...): its gradient accumulators belong to another stream and capturing a backward pass "
+                "through them would abort inside the HIP runtime. Drop those tensors (keep `loss.detach()` or "
+                "`float(loss)` instead) and build the GraphedTrainStep again.")
         self.graph = torch.cuda.CUDAGraph()
         optimizer.zero_grad(set_to_none=True)
         with torch.cuda.graph(self.graph):

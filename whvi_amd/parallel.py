@@ -19,7 +19,7 @@ import torch
 import torch.distributed as dist
 
 __all__ = ["init_from_env", "shard_bounds", "fwht_row_shard", "gather_predictions",
-           "mc_sharded_forward", "all_reduce_grads", "sample_seed"]
+           "mc_sharded_forward", "all_reduce_grads", "sample_seed", "seed_inkernel_rng"]
 
 
 def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, torch.device]:
@@ -48,6 +48,12 @@ def _world() -> Tuple[int, int]:
     return 0, 1
 
 
+def _in_group() -> bool:
+    """True inside an initialised process group -- of ANY size: a one-rank group still runs its collectives (through
+    RCCL on a GPU), which is how the single-GPU box exercises the N > 1 code path (tests/test_rccl_gpu.py)."""
+    return dist.is_available() and dist.is_initialized()
+
+
 def shard_bounds(n: int, rank: int, world: int) -> Tuple[int, int]:
     """[begin, end) of a balanced contiguous partition of n units (the first n % world ranks get
     one extra unit).  Units are rows or MC samples."""
@@ -68,12 +74,29 @@ def sample_seed(base_seed: int, rank: int) -> int:
     return (int(base_seed) * 1_000_003 + 7919 * (rank + 1)) % (2 ** 63 - 1)
 
 
+def seed_inkernel_rng(net: torch.nn.Module, base_seed: int, rank: int = None) -> int:
+    """Give every layer that draws eps inside the reparameterisation kernel (``net.set_inkernel_rng()``) a fresh
+    Philox state whose seed depends on (base_seed, RANK, layer index), offset 0.  torch's generators do not reach
+    that stream, so without this all ranks of a job started from one ``torch.manual_seed`` would draw identical eps.
+    Returns the number of layers seeded."""
+    from whvi_amd import _hip
+    r = _world()[0] if rank is None else rank
+    count = 0
+    for index, module in enumerate(net.modules()):
+        if getattr(module, "inkernel_rng", False) and hasattr(type(module), "inkernel_rng"):
+            device = next(module.parameters()).device
+            seed = (sample_seed(base_seed, r) + 104_729 * (index + 1)) % (2 ** 62)
+            module._rng_state = _hip.new_rng_state(device, seed=seed)
+            count += 1
+    return count
+
+
 def gather_predictions(local: torch.Tensor, counts=None) -> torch.Tensor:
     """All-gather per-rank predictions ``(batch, n_out, S_local)`` into ``(batch, n_out, S)`` with
     rank-major sample order.  ``counts`` (samples per rank) allows ragged shards; ranks with fewer
     samples are padded for the collective and trimmed afterwards."""
     rank, world = _world()
-    if world == 1:
+    if not _in_group():
         return local
     s_local = local.size(2)
     if counts is None:
@@ -108,6 +131,7 @@ def mc_sharded_forward(net, x: torch.Tensor, n_samples: int, base_seed: int = 0)
     n_local = end - begin
     with torch.random.fork_rng(devices=devices):
         torch.manual_seed(sample_seed(base_seed, rank))
+        seed_inkernel_rng(net, base_seed, rank)      # the opt-in Philox stream: per rank too, same determinism
         if n_local == 0:
             n_out = net.sequential(x).size(-1)
             local = torch.zeros(x.size(0), n_out, 0, dtype=x.dtype, device=x.device)
@@ -126,17 +150,24 @@ def all_reduce_grads(module: torch.nn.Module, average: bool = True) -> None:
     """Sum (or average) parameter gradients over ranks in ONE flattened all-reduce -- the WHVI
     parameters are a handful of length-D vectors, so bucketing per tensor would be latency-bound."""
     rank, world = _world()
-    if world == 1:
+    if not _in_group():
         return
-    grads = [p.grad for p in module.parameters() if p.grad is not None]
-    if not grads:
+    # every rank sends the SAME layout: all parameters that require a gradient, zeros where this rank has none
+    # (a shard with no samples, a parameter its local pass did not touch) -- never a rank-dependent subset, never a
+    # skipped collective, or the other ranks would block or mismatch sizes
+    params = [p for p in module.parameters() if p.requires_grad]
+    if not params:
         return
-    flat = torch.cat([g.reshape(-1) for g in grads])
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     if average:
         flat /= world
     offset = 0
-    for g in grads:
-        n = g.numel()
-        g.copy_(flat[offset:offset + n].view_as(g))
+    for p in params:
+        n = p.numel()
+        piece = flat[offset:offset + n].view_as(p)
+        if p.grad is None:
+            p.grad = piece.clone()
+        else:
+            p.grad.copy_(piece)
         offset += n

@@ -138,7 +138,12 @@ class ReparamKLFunction(torch.autograd.Function):
         if not torch.is_grad_enabled():
             grad_mu, grad_rho = _hip.reparam_kl_bwd(grad_u, grad_kl, g_mu, g_rho, eps, sigma, lam)
             return grad_mu, grad_rho, grad_eps, None
-        # create_graph=True: the same closed form as differentiable ops
+        # create_graph=True: the same closed form as differentiable ops.  sigma is recomputed from g_rho: the saved
+        # one is a kernel output without a grad_fn, and both 1 / sigma below and grad_eps = grad_u * sigma must
+        # stay differentiable with respect to g_rho for second derivatives (Hessians, gradient penalties)
+        sigma = F.softplus(g_rho)
+        if ctx.needs_input_grad[2] and grad_u is not None:
+            grad_eps = grad_u[:, 1:] * sigma.unsqueeze(1)
         gk = (torch.zeros_like(g_mu[:, 0]) if grad_kl is None else grad_kl).unsqueeze(-1)
         gu = torch.zeros_like(g_mu).unsqueeze(1).expand(-1, eps.shape[1] + 1, -1) if grad_u is None else grad_u
         grad_mu = gu[:, 0] + gk * (g_mu / lam)
@@ -182,6 +187,18 @@ def _reparam(g_mu, g_rho, eps, lambda_):
     return torch.cat((g_mu.unsqueeze(1), sigma.unsqueeze(1) * eps), dim=1), None
 
 
+def _fresh_philox_seed():
+    """Seed of a layer's in-kernel generator: drawn from torch's default CPU generator (so ``torch.manual_seed`` makes
+    runs repeatable) and, inside a ``torch.distributed`` job, mixed with the RANK -- ranks usually share one
+    ``manual_seed`` so that their initial parameters agree, and would otherwise all draw the same eps, turning the
+    gathered Monte-Carlo samples into ``world`` copies of one shard."""
+    import torch.distributed as dist
+    seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    if dist.is_available() and dist.is_initialized():
+        seed = (seed + 0x9E3779B97F4A7C15 * (dist.get_rank() + 1)) % (2 ** 62)
+    return seed
+
+
 def _draw_and_reparam(module, g_mu, g_rho, n_samples, lambda_):
     """(u (J, 1+S, D), kl) for a batched MC pass.  Default: one ``torch.randn(J, S, D)`` draw (the stream the
     parity tests replay) followed by ``_reparam``.  With ``module.inkernel_rng`` on a GPU the draw happens inside
@@ -191,7 +208,7 @@ def _draw_and_reparam(module, g_mu, g_rho, n_samples, lambda_):
         from whvi_amd import _hip
         state = getattr(module, "_rng_state", None)
         if state is None or state.device != g_mu.device:
-            state = module._rng_state = _hip.new_rng_state(g_mu.device)
+            state = module._rng_state = _hip.new_rng_state(g_mu.device, seed=_fresh_philox_seed())
         return ReparamKLPhiloxFunction.apply(g_mu, g_rho, state, n_samples, lambda_)
     eps = torch.randn(J, n_samples, D, device=g_mu.device)
     return _reparam(g_mu, g_rho, eps, lambda_)
