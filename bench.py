@@ -298,11 +298,11 @@ def _extra_f16(device):
     """BASELINE config 5 (one GPU's share): D = 4096 fp16, 2^20 rows = 8 GiB."""
     from whvi_amd import _hip
     x = (torch.randn(1 << 20, 4096, device=device) * 2.0 ** -8).half()
-    # two in-place transforms multiply the data by 4096, which fp16 (max 65504) survives once: every second launch is
-    # followed by an exact 2^-12 rescale, and each transform is timed by its own event pair so the rescale is in
-    # neither the count nor the time
-    res = _rate(1 << 20, 4096, 2, event_ms_each(lambda: _hip.fwht_rows(x, out=x), lambda i: x.mul_(2.0 ** -12) if i & 1 else None,
-                                                iters=10, warm=10))
+    for _ in range(12):                       # clock ramp; these launches overflow fp16 (x 64 per transform) -- untimed
+        _hip.fwht_rows(x, out=x)
+    # fp16 spans 2^-24 .. 2^16: refill with small values so the timed in-place launches (x 2^6 each) stay in range
+    x.view(256, 4096, 4096).copy_(torch.randn(4096, 4096, device=device).mul_(2.0 ** -16).half())
+    res = _rate(1 << 20, 4096, 2, event_ms(lambda: _hip.fwht_rows(x, out=x), iters=4, warm=0))
     res.update(kernel=_hip.last_kernel(), values_finite=_finite(x))
     return res
 
@@ -323,6 +323,31 @@ def _extra_fused(device):
     res["note"] = ("one fused launch = 2 FWHTs + 3 scalings per row; unfused (2 FWHT launches + 3 elementwise) "
                    "moves 5x the bytes")
     return res
+
+
+def _extra_wbar_bwd(device):
+    """Backward of the weight construction (whvi_wbar_bwd, src/weights.py:73 under autograd): one launch reads dL/dW
+    once.  D = 2048 x 64 matrices (1 GiB of gradient; the fused kernel's config-3 shape) and 4 GiB, and config 2's
+    backward (D = 512 x 32 samples, 32 MiB: cache-resident, launch-latency-sized).  Algorithmic bytes = the gradient
+    read once (the 3 x D outputs per matrix are 1/D of it)."""
+    from whvi_amd import _hip
+    out = {}
+    for key, (J, S, D, mean) in (("D2048_x64_1GiB", (1, 64, 2048, False)), ("D2048_x64_mean_1GiB", (1, 64, 2048, True)),
+                                 ("D2048_x256_4GiB", (1, 256, 2048, False)), ("D512_x32_mean_config2", (1, 32, 512, True))):
+        U = S + 1 if mean else S
+        s1, s2, u = torch.randn(J, D, device=device), torch.randn(J, D, device=device), torch.randn(J, U, D, device=device)
+        gw = torch.randn(J, S, D, D, device=device)
+        res = [None]
+
+        def run():
+            res[0] = _hip.wbar_bwd(gw, s1, u, s2, mean=mean)
+        ms = event_ms(run, iters=20, warm=20)
+        gbs = gw.numel() * 4 / (ms * 1e-3) / 1e9
+        out[key] = {"matrices": J * S, "D": D, "ms": round(ms, 4), "GB_per_s": round(gbs, 1),
+                    "frac_of_peak": round(gbs / HBM_PEAK_GBS, 4), "kernel": _hip.last_kernel(),
+                    "values_finite": bool(torch.isfinite(res[0][:, :, 1:] if mean else res[0]).all())}
+        del gw
+    return out
 
 
 def _extra_layer(device):
@@ -447,7 +472,8 @@ def extras(device):
     recorded under its own key and never costs the other numbers or the headline line."""
     out = {}
     for key, fn in (("fwht_f32_sweep_4GiB", _extra_sweep), ("fwht_f16_D4096_2^20rows", _extra_f16),
-                    ("fused_shs_D2048_S64_B8192", _extra_fused), ("whvilinear_512_fwd_kl_32mc_b4096", _extra_layer),
+                    ("fused_shs_D2048_S64_B8192", _extra_fused), ("wbar_bwd", _extra_wbar_bwd),
+                    ("whvilinear_512_fwd_kl_32mc_b4096", _extra_layer),
                     ("whviregression_3_1024_1024_1_mc16", _extra_network), ("toy_regression", _extra_toy)):
         try:
             out[key] = fn(device)

@@ -194,7 +194,9 @@ int whvi_wbar_fwd_f64(void *dst, const void *s1, const void *u, const void *s2, 
  *   outputs are (J, 1 + S, D); rows 1..S are written (part_s1 / part_s2 include the mean vector's share) and row 0 is
  *   left to the caller: the sum over k of rows 1..S is dL/du[j,0] resp. the per-matrix totals.
  * log2d in [2, 13] (f32) / [1, 12] (f64). */
-#define WHVI_WBAR_MEAN 1
+#define WHVI_WBAR_MEAN   1
+#define WHVI_WBAR_NO_LDS 2   /* tuning / cross-check: butterflies through the DPP network instead of the LDS-staged one
+                              * (same adds in the same order: identical transform bits) */
 int whvi_wbar_bwd_f32(void *grad_u, void *part_s1, void *part_s2, const void *grad_w, const void *s1,
                       const void *u, const void *s2, int64_t J, int64_t S, int64_t R, int32_t log2d,
                       int32_t flags, void *stream);

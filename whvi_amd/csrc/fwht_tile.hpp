@@ -200,6 +200,35 @@ __device__ __forceinline__ void bfly2(A &lo0, A &lo1, A &hi0, A &hi1)
     }
 }
 
+// Two independent products / sums as ONE v_pk_mul_f32 / v_pk_add_f32 (f32; plain ops otherwise): (x0, x1) *= (m0, m1)
+// and (a0, a1) += (x0, x1).  Separate IEEE roundings per element, like the scalar forms.
+template <typename A>
+__device__ __forceinline__ void mul2(A &x0, A &x1, A m0, A m1)
+{
+    if constexpr (std::is_same<A, float>::value) {
+        f32x2 x = {x0, x1}, m = {m0, m1};
+        x = m * x;
+        x0 = x[0];
+        x1 = x[1];
+    } else {
+        x0 = m0 * x0;
+        x1 = m1 * x1;
+    }
+}
+template <typename A>
+__device__ __forceinline__ void add2(A &a0, A &a1, A x0, A x1)
+{
+    if constexpr (std::is_same<A, float>::value) {
+        f32x2 a = {a0, a1}, x = {x0, x1};
+        a = a + x;
+        a0 = a[0];
+        a1 = a[1];
+    } else {
+        a0 = a0 + x0;
+        a1 = a1 + x1;
+    }
+}
+
 // One full FWHT of every 2^LOG2D-element row held in r[K][VEC] (layout above).
 // PK (bit mask: 1 = in-chunk stages, 2 = permlane-swap stages, 4 = k-bit stages): issue those stages of f32 tiles as v_pk_add_f32 pairs.  Same bits either way.  Packed adds halve
 // the issue slots of those stages but want even-aligned register pairs: in the plain streaming kernel that costs

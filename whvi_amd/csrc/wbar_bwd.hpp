@@ -18,15 +18,46 @@
 
 namespace whvi {
 
-template <typename A> __device__ __forceinline__ A flip_if(A v, bool neg) { return neg ? -v : v; }
+// One xor-butterfly step of a wave all-reduce: every lane ends up with v(lane) + v(lane ^ (1 << LB)).  Lane bits 0..3
+// go through the DPP network, bits 4 / 5 through v_permlane16/32_swap on a copy (a' + b' holds the sum of the two
+// 16-lane rows / 32-lane halves in every lane) -- no ds_bpermute round trips through the LDS pipeline.
+template <int LB, typename A>
+__device__ __forceinline__ A xor_reduce_step(A v)
+{
+    if constexpr (LB < 4) {
+        return v + Bits<A>::template partner_dpp<LB>(v);
+    } else {
+        A a = v, b = v;
+        swap_pair<(LB == 4) ? 16 : 32>(a, b);
+        return a + b;
+    }
+}
+
+template <typename A> __device__ __forceinline__ A sign_flip(A v, uint32_t sign_bit)    // sign_bit: 0 or 0x80000000
+{
+    return Bits<A>::fold_sign(v, sign_bit);
+}
+__device__ __forceinline__ uint32_t parity_sign(uint32_t x) { return (uint32_t)(__builtin_popcount(x) & 1) << 31; }
 
 // Tile ownership and index helpers as in fused_shs_kernel.  Rows are (J, S, R) x D, s1 / s2 are (J, D),
 // u is (J, S, D) -- or (J, 1 + S, D) with MEAN, row 0 of each j being the mean vector added to every sample's
 // matrix -- and the outputs are laid out like u (first R entries of rows 1.. written; MEAN leaves row 0 to the caller's sum).
-template <typename T, int LOG2D, int K, bool NT, bool MEAN>
+//
+// Structure (round 2; the round-1 kernel sat at 0.47 of the HBM peak and was VALU-bound: ~1900 VALU instructions per
+// 16 KiB tile cap a CU at 1.2 tiles / us = 5.0 TB/s for the chip -- profiles/r02/wbar_bwd_*):
+//   * every row's scalars (s1, u, u_mean, s2, the diagonal element of dL/dW, its indices) are fetched ONCE, up front,
+//     next to the tile loads -- wave-uniform (scalar loads) for rows of >= 64 chunks;
+//   * POLICY_LDS (f32, 64-register tiles): the six lane-bit stages of the transform run as packed in-register adds
+//     after one transpose through a private LDS slab (fwht_tile_lds: a third of the DPP network's issue slots);
+//   * the three signed row sums share one pass: the Hadamard sign (-1)^popcount(i & d) splits into an in-chunk part
+//     folded into the multipliers (+/- s2_i, +/- u_i, +/- u0_i per position: (-s) * g == -(s * g) exactly), a per-chunk
+//     part applied to the chunk's partial sums and a per-lane part applied once before the cross-lane reduction;
+//     products stay separate roundings (built with -ffp-contract=off), packed two per instruction;
+//   * cross-lane sums through DPP / permlane swaps (xor_reduce_step).
+template <typename T, int LOG2D, int K, bool NT, bool MEAN, int POLICY>
 __global__ void __launch_bounds__(256)
-wbar_bwd_kernel(T *grad_u, T *part_s1, T *part_s2, const u32x4 *gw, const T *s1, const T *u, const T *s2,
-                int64_t n_chunks, int64_t n_tiles, uint32_t n_rows, FastDiv by_r, FastDiv by_s)
+wbar_bwd_kernel(T *grad_u, T *part_s1, T *part_s2, const u32x4 *gw, const T *__restrict__ s1, const T *__restrict__ u,
+                const T *__restrict__ s2, int64_t n_chunks, int64_t n_tiles, uint32_t n_rows, FastDiv by_r, FastDiv by_s)
 {
     using E = Elem<T>;
     using A = typename E::acc;
@@ -46,7 +77,9 @@ wbar_bwd_kernel(T *grad_u, T *part_s1, T *part_s2, const u32x4 *gw, const T *s1,
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t t = (int64_t)blockIdx.x * 4 + wave;
+    int64_t blk = blockIdx.x;
+    if (NT && (gridDim.x & 7) == 0) blk = (blk & 7) * (int64_t)(gridDim.x >> 3) + (blk >> 3);   // XCD-contiguous
+    const int64_t t = blk * 4 + wave;
     if (t >= n_tiles) return;
 
     const int64_t base = t * TILE;
@@ -56,107 +89,147 @@ wbar_bwd_kernel(T *grad_u, T *part_s1, T *part_s2, const u32x4 *gw, const T *s1,
         if constexpr (SH >= 6) return row0 + (uint32_t)((k * 64) >> SH);                 // wave-uniform
         else return row0 + (uint32_t)((k * 64 + lane) >> SH);
     };
-    auto chunk_col = [&](int k) -> uint32_t { return (uint32_t)(k * 64 + lane) & (CPR - 1); };
+    const uint32_t lane_col = (uint32_t)lane & (CPR - 1);        // chunk column of this lane within its row (+ kk * 64)
+
+    // ---- tile loads first, then every row's scalars: all of it in flight together
+    u32x4 raw[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        u32x4 z = {0u, 0u, 0u, 0u};
+        raw[k] = (full || base + k * 64 + lane < n_chunks) ? ld16<NT>(gw + base + k * 64 + lane) : z;
+    }
     // scalar operands of a row; rows past the end read row 0's (valid memory, results discarded)
-    struct RowIdx { uint32_t i, jk, j, ur, u0; };   // row i of matrix (j, k); jk = j * S + k; ur / u0: rows of u
-    auto row_index = [&](uint32_t row) -> RowIdx {
+    uint32_t ri[NACC];           // row index i inside its matrix
+    size_t ro[NACC];             // offset of the row's three outputs (laid out like u)
+    A s1v[NACC], uv[NACC], uv0[NACC], s2v[NACC], gii[NACC];
+#pragma unroll
+    for (int n = 0; n < NACC; ++n) {
+        const uint32_t row = chunk_row(n * KPR);
         const uint32_t rr = row < n_rows ? row : 0u;
         const uint32_t jk = by_r.div(rr);
         const uint32_t i = rr - jk * by_r.d;
         const uint32_t j = by_s.div(jk);
         // MEAN: u is (J, 1 + S, D) = [u_mean; u_1 .. u_S] and W[j,k] = w_bar(u_mean) + w_bar(u_k)
-        return RowIdx{i, jk, j, MEAN ? jk + j + 1 : jk, MEAN ? j * by_s.d + j : 0u};
-    };
+        const uint32_t ur = MEAN ? jk + j + 1 : jk;
+        ri[n] = i;
+        ro[n] = (size_t)ur * D + i;
+        s1v[n] = (A)s1[(size_t)j * D + i];
+        s2v[n] = (A)s2[(size_t)j * D + i];
+        uv[n] = (A)u[(size_t)ur * D + i];
+        if constexpr (MEAN) uv0[n] = (A)u[(size_t)(j * by_s.d + j) * D + i];
+        else uv0[n] = (A)0;
+        gii[n] = (A)reinterpret_cast<const T *>(gw)[(size_t)rr * D + i];      // dL/dW[row, i]: a line this tile loads anyway
+    }
 
     A r[K][VEC];
-    {
-        u32x4 raw[K];
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            u32x4 z = {0u, 0u, 0u, 0u};
-            raw[k] = (full || base + k * 64 + lane < n_chunks) ? ld16<NT>(gw + base + k * 64 + lane) : z;
-        }
+    for (int k = 0; k < K; ++k) {
+        E::unpack(raw[k], r[k]);
+        const A sv = s1v[k / KPR];
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const RowIdx x = row_index(chunk_row(k));
-            const A s1v = (A)s1[(size_t)x.j * D + x.i];
-            E::unpack(raw[k], r[k]);
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) r[k][e] = s1v * r[k][e];
-        }
+        for (int e = 0; e < VEC; e += 2) mul2(r[k][e], r[k][e + 1], sv, sv);
     }
-    fwht_tile<A, VEC, K, LOG2D, POLICY_DPP, 0>(r, lane);       // g1
+    if constexpr (POLICY == POLICY_LDS) {
+        extern __shared__ __attribute__((aligned(16))) char whvi_smem[];
+        fwht_tile_lds<A, VEC, K, LOG2D>(r, lane, reinterpret_cast<A *>(whvi_smem) + wave * lds_slab_floats<VEC, K>());
+    } else {
+        fwht_tile<A, VEC, K, LOG2D, POLICY_DPP, 0>(r, lane);       // g1
+    }
 
-    A acc_u[NACC], acc_s2[NACC];
+    // ---- the row sums  dL/du = sum_d g1[d] * (H[i,d] s2_i)  and  dL/ds2 = sum_d H[d,i] * (u_i g1[d]) (+ u0_i g1[d])
+    // H[i,d] = (-1)^popcount(i & d) with d = (kk * 64 + lane_col) * VEC + e
 #pragma unroll
     for (int n = 0; n < NACC; ++n) {
-        const RowIdx x = row_index(chunk_row(n * KPR));
-        const A uv = (A)u[(size_t)x.ur * D + x.i];
-        const A uv0 = MEAN ? (A)u[(size_t)x.u0 * D + x.i] : (A)0;
-        const A s2v = (A)s2[(size_t)x.j * D + x.i];
-        A su = (A)0, ss = (A)0;
-        // H[i,d] = (-1)^popcount(i & d) with d = dbase + e, dbase a multiple of VEC: the parity splits into one term
-        // per chunk and one per in-chunk position, and the sign goes onto g1 once ((-g) * s == -(g * s) exactly)
-        bool par_e[VEC];
+        const uint32_t i = ri[n];
+        A m1[VEC], m2[VEC], m3[VEC];          // multipliers with the in-chunk sign folded in
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) par_e[e] = __builtin_popcount(x.i & (uint32_t)e) & 1;
+        for (int e = 0; e < VEC; ++e) {
+            const uint32_t se = parity_sign(i & (uint32_t)e);
+            m1[e] = sign_flip(s2v[n], se);
+            m2[e] = sign_flip(uv[n], se);
+            m3[e] = sign_flip(uv0[n], se);
+        }
+        A su[2] = {(A)0, (A)0}, ss[2] = {(A)0, (A)0};
 #pragma unroll
         for (int kk = 0; kk < KPR; ++kk) {
             const int k = n * KPR + kk;
-            const bool par_k = __builtin_popcount(x.i & (chunk_col(k) * VEC)) & 1;
+            A pu[2] = {(A)0, (A)0}, ps[2] = {(A)0, (A)0};
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                const A g = flip_if(r[k][e], par_k != par_e[e]);
-                su += g * s2v;
-                ss += uv * g;
-                if constexpr (MEAN) ss += uv0 * g;
+            for (int e = 0; e < VEC; e += 2) {
+                A a0 = r[k][e], a1 = r[k][e + 1];
+                mul2(a0, a1, m1[e], m1[e + 1]);                      // g * (+/- s2_i)
+                add2(pu[0], pu[1], a0, a1);
+                A b0 = r[k][e], b1 = r[k][e + 1];
+                mul2(b0, b1, m2[e], m2[e + 1]);                      // (+/- u_i) * g
+                add2(ps[0], ps[1], b0, b1);
+                if constexpr (MEAN) {
+                    A c0 = r[k][e], c1 = r[k][e + 1];
+                    mul2(c0, c1, m3[e], m3[e + 1]);                  // (+/- u0_i) * g
+                    add2(ps[0], ps[1], c0, c1);
+                }
+            }
+            if constexpr (KPR > 1) {
+                const uint32_t sk = parity_sign(i & ((uint32_t)kk * 64u * VEC));       // wave-uniform
+                add2(su[0], su[1], sign_flip(pu[0], sk), sign_flip(pu[1], sk));
+                add2(ss[0], ss[1], sign_flip(ps[0], sk), sign_flip(ps[1], sk));
+            } else {
+                su[0] = pu[0]; su[1] = pu[1]; ss[0] = ps[0]; ss[1] = ps[1];
             }
         }
-#pragma unroll
-        for (int lb = 0; lb < LANE_BITS; ++lb) {
-            su += __shfl_xor(su, 1 << lb, 64);
-            ss += __shfl_xor(ss, 1 << lb, 64);
-        }
-        acc_u[n] = su;
-        acc_s2[n] = ss;
-    }
-    // one lane per row writes the three results
-#pragma unroll
-    for (int n = 0; n < NACC; ++n) {
+        const uint32_t sl = parity_sign(i & (lane_col * VEC));
+        A tu = sign_flip(su[0] + su[1], sl), ts = sign_flip(ss[0] + ss[1], sl);
+        static_for<0, LANE_BITS>([&](auto lb) {
+            tu = xor_reduce_step<decltype(lb)::value>(tu);
+            ts = xor_reduce_step<decltype(lb)::value>(ts);
+        });
+        // one lane per row writes the three results (outputs are laid out like u; entries i >= R stay untouched)
         const uint32_t row = chunk_row(n * KPR);
-        const bool writer = (SH >= 6) ? (lane == 0) : ((lane & (int)(CPR - 1)) == 0);
+        const bool writer = (SH >= 6) ? (lane == 0) : (lane_col == 0);
         if (writer && row < n_rows) {
-            const RowIdx x = row_index(row);
-            const A uv = (A)u[(size_t)x.ur * D + x.i];
-            const A s2v = (A)s2[(size_t)x.j * D + x.i];
-            const A gii = (A)reinterpret_cast<const T *>(gw)[(size_t)row * D + x.i];
-            const size_t o = (size_t)x.ur * D + x.i;          // outputs are laid out like u; entries i >= R stay untouched
-            A p1 = gii * ((A)D * (uv * s2v));
-            if constexpr (MEAN) p1 += gii * ((A)D * ((A)u[(size_t)x.u0 * D + x.i] * s2v));
-            grad_u[o] = (T)acc_u[n];
-            part_s2[o] = (T)acc_s2[n];
-            part_s1[o] = (T)p1;
+            A p1 = gii[n] * ((A)D * (uv[n] * s2v[n]));
+            if constexpr (MEAN) p1 += gii[n] * ((A)D * (uv0[n] * s2v[n]));
+            grad_u[ro[n]] = (T)tu;
+            part_s2[ro[n]] = (T)ts;
+            part_s1[ro[n]] = (T)p1;
         }
     }
 }
 
 template <typename T, int LOG2D>
 inline void launch_wbar_bwd(void *grad_u, void *part_s1, void *part_s2, const void *gw, const void *s1,
-                            const void *u, const void *s2, int64_t rows, int64_t S, int64_t R, bool mean, hipStream_t st)
+                            const void *u, const void *s2, int64_t rows, int64_t S, int64_t R, bool mean, bool no_lds,
+                            hipStream_t st)
 {
     constexpr int K = pick_k<T, LOG2D>();
     constexpr int VEC = Elem<T>::VEC;
+    using A = typename Elem<T>::acc;
     const int64_t n_chunks = (rows << LOG2D) / VEC;
     const int64_t n_tiles = (n_chunks + 64 * K - 1) / (64 * K);
     const FastDiv dr = make_fastdiv((uint32_t)R), ds = make_fastdiv((uint32_t)S);
     const unsigned grid = (unsigned)((n_tiles + 3) / 4);
-#define WHVI_BWD(NT, MEAN)                                                                                       \
-    hipLaunchKernelGGL((wbar_bwd_kernel<T, LOG2D, K, NT, MEAN>), dim3(grid), dim3(256), 0, st, (T *)grad_u,      \
-                       (T *)part_s1, (T *)part_s2, (const u32x4 *)gw, (const T *)s1, (const T *)u,         \
-                       (const T *)s2, n_chunks, n_tiles, (uint32_t)rows, dr, ds)
-    const bool nt = n_chunks * 16 >= NT_MIN_BYTES;
-    if (mean) { if (nt) WHVI_BWD(true, true); else WHVI_BWD(false, true); }
-    else { if (nt) WHVI_BWD(true, false); else WHVI_BWD(false, false); }
+    // the LDS-staged network needs 32-bit arithmetic and a 64-register tile; rows of at least 64 chunks make the
+    // transposes worth it (below that few lane-bit stages exist and the DPP network is short)
+    constexpr bool LDS_OK = sizeof(A) == 4 && K * VEC == 64 && LOG2D >= 8;
+    constexpr size_t slab_bytes = (size_t)K * (64 * VEC + VEC) * 4;
+#define WHVI_BWD(NT, MEAN, POL)                                                                                  \
+    do {                                                                                                         \
+        note_launch<T>("wbar_bwd_kernel", LOG2D, K, (bool)NT, (bool)MEAN, (int)POL);                             \
+        hipLaunchKernelGGL((wbar_bwd_kernel<T, LOG2D, K, NT, MEAN, POL>), dim3(grid), dim3(256),                 \
+                           (POL == POLICY_LDS) ? 4 * slab_bytes : 0, st, (T *)grad_u, (T *)part_s1, (T *)part_s2, \
+                           (const u32x4 *)gw, (const T *)s1, (const T *)u, (const T *)s2, n_chunks, n_tiles,     \
+                           (uint32_t)rows, dr, ds);                                                              \
+    } while (0)
+#define WHVI_BWD_POL(NT, MEAN)                                           \
+    do {                                                                 \
+        if constexpr (LDS_OK) {                                          \
+            if (!no_lds) { WHVI_BWD(NT, MEAN, POLICY_LDS); break; }      \
+        }                                                                \
+        WHVI_BWD(NT, MEAN, POLICY_DPP);                                  \
+    } while (0)
+    const bool nt = n_chunks * 16 > NT_MIN_BYTES;      // a read-only stream: non-temporal beyond the Infinity Cache
+    if (mean) { if (nt) WHVI_BWD_POL(true, true); else WHVI_BWD_POL(false, true); }
+    else { if (nt) WHVI_BWD_POL(true, false); else WHVI_BWD_POL(false, false); }
+#undef WHVI_BWD_POL
 #undef WHVI_BWD
 }
 
@@ -168,7 +241,7 @@ inline int wbar_bwd_dispatch(void *grad_u, void *part_s1, void *part_s2, const v
     constexpr int LV = ilog2(Elem<T>::VEC);
     g_err[0] = 0;
     if (J < 0 || S < 0 || R < 0) return fail(WHVI_ERR_ARG, "whvi_wbar_bwd: negative size%s", "");
-    if (flags & ~WHVI_WBAR_MEAN) return fail(WHVI_ERR_ARG, "whvi_wbar_bwd: unknown flags%s 0x%llx", "", flags);
+    if (flags & ~(WHVI_WBAR_MEAN | WHVI_WBAR_NO_LDS)) return fail(WHVI_ERR_ARG, "whvi_wbar_bwd: unknown flags%s 0x%llx", "", flags);
     if (log2d < LV || log2d > max_single_pass_log2d<T>())
         return fail(WHVI_ERR_SIZE, "whvi_wbar_bwd: log2(D)%s = %lld is outside the supported range [%lld, ...]", "",
                     log2d, LV);
@@ -183,7 +256,8 @@ inline int wbar_bwd_dispatch(void *grad_u, void *part_s1, void *part_s2, const v
 #define WHVI_CASE(L)                                                                                       \
     case L:                                                                                                \
         if constexpr (L >= LV && L <= max_single_pass_log2d<T>())                                          \
-            launch_wbar_bwd<T, L>(grad_u, part_s1, part_s2, gw, s1, u, s2, rows, S, R, (flags & WHVI_WBAR_MEAN) != 0, st);                 \
+            launch_wbar_bwd<T, L>(grad_u, part_s1, part_s2, gw, s1, u, s2, rows, S, R, (flags & WHVI_WBAR_MEAN) != 0,      \
+                                  (flags & WHVI_WBAR_NO_LDS) != 0, st);                 \
         break;
     switch (log2d) {
         WHVI_CASE(1) WHVI_CASE(2) WHVI_CASE(3) WHVI_CASE(4) WHVI_CASE(5) WHVI_CASE(6) WHVI_CASE(7)
