@@ -54,8 +54,11 @@ __device__ __forceinline__ uint32_t parity_sign(uint32_t x) { return (uint32_t)(
 //     part applied to the chunk's partial sums and a per-lane part applied once before the cross-lane reduction;
 //     products stay separate roundings (built with -ffp-contract=off), packed two per instruction;
 //   * cross-lane sums through DPP / permlane swaps (xor_reduce_step).
-template <typename T, int LOG2D, int K, bool NT, bool MEAN, int POLICY>
-__global__ void __launch_bounds__(256)
+//   * PIPE (LDS policy, big problems): the LDS slabs cap a CU at 8 waves, far fewer than its registers allow, so the
+//     spare registers hold the NEXT tile: a persistent grid (2 blocks per CU) walks the tiles with a grid stride and
+//     every wave issues tile t + stride's loads (data and row scalars) before it transforms tile t.
+template <typename T, int LOG2D, int K, bool NT, bool MEAN, int POLICY, bool PIPE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE ? 2 : 1)))
 wbar_bwd_kernel(T *grad_u, T *part_s1, T *part_s2, const u32x4 *gw, const T *__restrict__ s1, const T *__restrict__ u,
                 const T *__restrict__ s2, int64_t n_chunks, int64_t n_tiles, uint32_t n_rows, FastDiv by_r, FastDiv by_s)
 {
@@ -69,6 +72,7 @@ wbar_bwd_kernel(T *grad_u, T *part_s1, T *part_s2, const u32x4 *gw, const T *__r
     constexpr uint32_t CPR = 1u << SH;
     constexpr uint32_t D = 1u << LOG2D;
     static_assert(LOG2D >= LV, "rows of at least one chunk");
+    static_assert(!PIPE || SH >= 6, "the pipelined form keeps the next tile's row scalars in SGPRs: wave-uniform rows");
     // rows of one tile: SH >= 6 -> every row covers all 64 lanes and KPR = CPR/64 consecutive k;
     //                   SH <  6 -> every k holds 64/CPR rows side by side in the lanes
     constexpr int KPR = SH >= 6 ? (int)(CPR / 64) : 1;
@@ -78,119 +82,161 @@ wbar_bwd_kernel(T *grad_u, T *part_s1, T *part_s2, const u32x4 *gw, const T *__r
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int64_t blk = blockIdx.x;
-    if (NT && (gridDim.x & 7) == 0) blk = (blk & 7) * (int64_t)(gridDim.x >> 3) + (blk >> 3);   // XCD-contiguous
-    const int64_t t = blk * 4 + wave;
+    if (NT && !PIPE && (gridDim.x & 7) == 0) blk = (blk & 7) * (int64_t)(gridDim.x >> 3) + (blk >> 3);   // XCD-contiguous
+    int64_t t = blk * 4 + wave;
     if (t >= n_tiles) return;
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    const uint32_t lane_col = (uint32_t)lane & (CPR - 1);        // chunk column of this lane within its row (+ kk * 64)
 
-    const int64_t base = t * TILE;
-    const bool full = base + TILE <= n_chunks;
-    const uint32_t row0 = (uint32_t)(base >> SH);
-    auto chunk_row = [&](int k) -> uint32_t {
+    auto first_row = [&](int64_t tile, int k) -> uint32_t {
+        const uint32_t row0 = (uint32_t)((tile * TILE) >> SH);
         if constexpr (SH >= 6) return row0 + (uint32_t)((k * 64) >> SH);                 // wave-uniform
         else return row0 + (uint32_t)((k * 64 + lane) >> SH);
     };
-    const uint32_t lane_col = (uint32_t)lane & (CPR - 1);        // chunk column of this lane within its row (+ kk * 64)
-
-    // ---- tile loads first, then every row's scalars: all of it in flight together
-    u32x4 raw[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        u32x4 z = {0u, 0u, 0u, 0u};
-        raw[k] = (full || base + k * 64 + lane < n_chunks) ? ld16<NT>(gw + base + k * 64 + lane) : z;
-    }
-    // scalar operands of a row; rows past the end read row 0's (valid memory, results discarded)
-    uint32_t ri[NACC];           // row index i inside its matrix
-    size_t ro[NACC];             // offset of the row's three outputs (laid out like u)
-    A s1v[NACC], uv[NACC], uv0[NACC], s2v[NACC], gii[NACC];
-#pragma unroll
-    for (int n = 0; n < NACC; ++n) {
-        const uint32_t row = chunk_row(n * KPR);
-        const uint32_t rr = row < n_rows ? row : 0u;
+    // scalar operands of a tile's rows; rows past the end read row 0's (valid memory, results discarded)
+    struct Rows {
+        uint32_t ri[NACC];           // row index i inside its matrix
+        size_t ro[NACC];             // offset of the row's three outputs (laid out like u)
+        A uv[NACC], uv0[NACC], s2v[NACC], gii[NACC];
+    };
+    // rows past the end read row 0's operands (valid memory, results discarded)
+    auto row_index = [&](int64_t tile, int n, uint32_t &rr, uint32_t &i, uint32_t &j, uint32_t &ur) {
+        const uint32_t row = first_row(tile, n * KPR);
+        rr = row < n_rows ? row : 0u;
         const uint32_t jk = by_r.div(rr);
-        const uint32_t i = rr - jk * by_r.d;
-        const uint32_t j = by_s.div(jk);
-        // MEAN: u is (J, 1 + S, D) = [u_mean; u_1 .. u_S] and W[j,k] = w_bar(u_mean) + w_bar(u_k)
-        const uint32_t ur = MEAN ? jk + j + 1 : jk;
-        ri[n] = i;
-        ro[n] = (size_t)ur * D + i;
-        s1v[n] = (A)s1[(size_t)j * D + i];
-        s2v[n] = (A)s2[(size_t)j * D + i];
-        uv[n] = (A)u[(size_t)ur * D + i];
-        if constexpr (MEAN) uv0[n] = (A)u[(size_t)(j * by_s.d + j) * D + i];
-        else uv0[n] = (A)0;
-        gii[n] = (A)reinterpret_cast<const T *>(gw)[(size_t)rr * D + i];      // dL/dW[row, i]: a line this tile loads anyway
-    }
-
-    A r[K][VEC];
+        i = rr - jk * by_r.d;
+        j = by_s.div(jk);
+        ur = MEAN ? jk + j + 1 : jk;     // MEAN: u is (J, 1 + S, D) = [u_mean; u_1 .. u_S], W[j,k] = w_bar(u_mean) + w_bar(u_k)
+    };
+    // the tile itself and the one scalar its first step needs
+    auto fetch_data = [&](int64_t tile, u32x4 (&raw)[K], A (&s1v)[NACC]) {
+        const int64_t base = tile * TILE;
+        const bool full = base + TILE <= n_chunks;
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        E::unpack(raw[k], r[k]);
-        const A sv = s1v[k / KPR];
-#pragma unroll
-        for (int e = 0; e < VEC; e += 2) mul2(r[k][e], r[k][e + 1], sv, sv);
-    }
-    if constexpr (POLICY == POLICY_LDS) {
-        extern __shared__ __attribute__((aligned(16))) char whvi_smem[];
-        fwht_tile_lds<A, VEC, K, LOG2D>(r, lane, reinterpret_cast<A *>(whvi_smem) + wave * lds_slab_floats<VEC, K>());
-    } else {
-        fwht_tile<A, VEC, K, LOG2D, POLICY_DPP, 0>(r, lane);       // g1
-    }
-
-    // ---- the row sums  dL/du = sum_d g1[d] * (H[i,d] s2_i)  and  dL/ds2 = sum_d H[d,i] * (u_i g1[d]) (+ u0_i g1[d])
-    // H[i,d] = (-1)^popcount(i & d) with d = (kk * 64 + lane_col) * VEC + e
-#pragma unroll
-    for (int n = 0; n < NACC; ++n) {
-        const uint32_t i = ri[n];
-        A m1[VEC], m2[VEC], m3[VEC];          // multipliers with the in-chunk sign folded in
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            const uint32_t se = parity_sign(i & (uint32_t)e);
-            m1[e] = sign_flip(s2v[n], se);
-            m2[e] = sign_flip(uv[n], se);
-            m3[e] = sign_flip(uv0[n], se);
+        for (int k = 0; k < K; ++k) {
+            u32x4 z = {0u, 0u, 0u, 0u};
+            raw[k] = (full || base + k * 64 + lane < n_chunks) ? ld16<NT>(gw + base + k * 64 + lane) : z;
         }
-        A su[2] = {(A)0, (A)0}, ss[2] = {(A)0, (A)0};
 #pragma unroll
-        for (int kk = 0; kk < KPR; ++kk) {
-            const int k = n * KPR + kk;
-            A pu[2] = {(A)0, (A)0}, ps[2] = {(A)0, (A)0};
+        for (int n = 0; n < NACC; ++n) {
+            uint32_t rr, i, j, ur;
+            row_index(tile, n, rr, i, j, ur);
+            s1v[n] = (A)s1[(size_t)j * D + i];
+        }
+    };
+    // everything the row sums need: requested before the transform, consumed after it
+    auto fetch_rows = [&](int64_t tile, Rows &rw) {
 #pragma unroll
-            for (int e = 0; e < VEC; e += 2) {
-                A a0 = r[k][e], a1 = r[k][e + 1];
-                mul2(a0, a1, m1[e], m1[e + 1]);                      // g * (+/- s2_i)
-                add2(pu[0], pu[1], a0, a1);
-                A b0 = r[k][e], b1 = r[k][e + 1];
-                mul2(b0, b1, m2[e], m2[e + 1]);                      // (+/- u_i) * g
-                add2(ps[0], ps[1], b0, b1);
-                if constexpr (MEAN) {
-                    A c0 = r[k][e], c1 = r[k][e + 1];
-                    mul2(c0, c1, m3[e], m3[e + 1]);                  // (+/- u0_i) * g
-                    add2(ps[0], ps[1], c0, c1);
+        for (int n = 0; n < NACC; ++n) {
+            uint32_t rr, i, j, ur;
+            row_index(tile, n, rr, i, j, ur);
+            rw.ri[n] = i;
+            rw.ro[n] = (size_t)ur * D + i;
+            rw.s2v[n] = (A)s2[(size_t)j * D + i];
+            rw.uv[n] = (A)u[(size_t)ur * D + i];
+            if constexpr (MEAN) rw.uv0[n] = (A)u[(size_t)(j * by_s.d + j) * D + i];
+            else rw.uv0[n] = (A)0;
+            rw.gii[n] = (A)reinterpret_cast<const T *>(gw)[(size_t)rr * D + i];   // dL/dW[row, i]: a line this tile loads anyway
+        }
+    };
+    auto scale_in = [&](const u32x4 (&raw)[K], const A (&s1v)[NACC], A (&r)[K][VEC]) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            E::unpack(raw[k], r[k]);
+            const A sv = s1v[k / KPR];
+#pragma unroll
+            for (int e = 0; e < VEC; e += 2) mul2(r[k][e], r[k][e + 1], sv, sv);
+        }
+    };
+    auto transform = [&](A (&r)[K][VEC]) {
+        if constexpr (POLICY == POLICY_LDS) {
+            extern __shared__ __attribute__((aligned(16))) char whvi_smem[];
+            fwht_tile_lds<A, VEC, K, LOG2D>(r, lane, reinterpret_cast<A *>(whvi_smem) + wave * lds_slab_floats<VEC, K>());
+        } else {
+            fwht_tile<A, VEC, K, LOG2D, POLICY_DPP, 0>(r, lane);       // g1
+        }
+    };
+    // the row sums  dL/du = sum_d g1[d] * (H[i,d] s2_i)  and  dL/ds2 = sum_d H[d,i] * (u_i g1[d]) (+ u0_i g1[d]),
+    // H[i,d] = (-1)^popcount(i & d) with d = (kk * 64 + lane_col) * VEC + e; then one lane per row writes the results
+    auto sums_out = [&](int64_t tile, const Rows &rw, A (&r)[K][VEC]) {
+#pragma unroll
+        for (int n = 0; n < NACC; ++n) {
+            const uint32_t i = rw.ri[n];
+            A m1[VEC], m2[VEC], m3[VEC];          // multipliers with the in-chunk sign folded in
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const uint32_t se = parity_sign(i & (uint32_t)e);
+                m1[e] = sign_flip(rw.s2v[n], se);
+                m2[e] = sign_flip(rw.uv[n], se);
+                m3[e] = sign_flip(rw.uv0[n], se);
+            }
+            A su[2] = {(A)0, (A)0}, ss[2] = {(A)0, (A)0};
+#pragma unroll
+            for (int kk = 0; kk < KPR; ++kk) {
+                const int k = n * KPR + kk;
+                A pu[2] = {(A)0, (A)0}, ps[2] = {(A)0, (A)0};
+#pragma unroll
+                for (int e = 0; e < VEC; e += 2) {
+                    A a0 = r[k][e], a1 = r[k][e + 1];
+                    mul2(a0, a1, m1[e], m1[e + 1]);                      // g * (+/- s2_i)
+                    add2(pu[0], pu[1], a0, a1);
+                    A b0 = r[k][e], b1 = r[k][e + 1];
+                    mul2(b0, b1, m2[e], m2[e + 1]);                      // (+/- u_i) * g
+                    add2(ps[0], ps[1], b0, b1);
+                    if constexpr (MEAN) {
+                        A c0 = r[k][e], c1 = r[k][e + 1];
+                        mul2(c0, c1, m3[e], m3[e + 1]);                  // (+/- u0_i) * g
+                        add2(ps[0], ps[1], c0, c1);
+                    }
+                }
+                if constexpr (KPR > 1) {
+                    const uint32_t sk = parity_sign(i & ((uint32_t)kk * 64u * VEC));       // wave-uniform
+                    add2(su[0], su[1], sign_flip(pu[0], sk), sign_flip(pu[1], sk));
+                    add2(ss[0], ss[1], sign_flip(ps[0], sk), sign_flip(ps[1], sk));
+                } else {
+                    su[0] = pu[0]; su[1] = pu[1]; ss[0] = ps[0]; ss[1] = ps[1];
                 }
             }
-            if constexpr (KPR > 1) {
-                const uint32_t sk = parity_sign(i & ((uint32_t)kk * 64u * VEC));       // wave-uniform
-                add2(su[0], su[1], sign_flip(pu[0], sk), sign_flip(pu[1], sk));
-                add2(ss[0], ss[1], sign_flip(ps[0], sk), sign_flip(ps[1], sk));
-            } else {
-                su[0] = pu[0]; su[1] = pu[1]; ss[0] = ps[0]; ss[1] = ps[1];
+            const uint32_t sl = parity_sign(i & (lane_col * VEC));
+            A tu = sign_flip(su[0] + su[1], sl), ts = sign_flip(ss[0] + ss[1], sl);
+            static_for<0, LANE_BITS>([&](auto lb) {
+                tu = xor_reduce_step<decltype(lb)::value>(tu);
+                ts = xor_reduce_step<decltype(lb)::value>(ts);
+            });
+            // outputs are laid out like u; entries i >= R stay untouched
+            const uint32_t row = first_row(tile, n * KPR);
+            const bool writer = (SH >= 6) ? (lane == 0) : (lane_col == 0);
+            if (writer && row < n_rows) {
+                A p1 = rw.gii[n] * ((A)D * (rw.uv[n] * rw.s2v[n]));
+                if constexpr (MEAN) p1 += rw.gii[n] * ((A)D * (rw.uv0[n] * rw.s2v[n]));
+                grad_u[rw.ro[n]] = (T)tu;
+                part_s2[rw.ro[n]] = (T)ts;
+                part_s1[rw.ro[n]] = (T)p1;
             }
         }
-        const uint32_t sl = parity_sign(i & (lane_col * VEC));
-        A tu = sign_flip(su[0] + su[1], sl), ts = sign_flip(ss[0] + ss[1], sl);
-        static_for<0, LANE_BITS>([&](auto lb) {
-            tu = xor_reduce_step<decltype(lb)::value>(tu);
-            ts = xor_reduce_step<decltype(lb)::value>(ts);
-        });
-        // one lane per row writes the three results (outputs are laid out like u; entries i >= R stay untouched)
-        const uint32_t row = chunk_row(n * KPR);
-        const bool writer = (SH >= 6) ? (lane == 0) : (lane_col == 0);
-        if (writer && row < n_rows) {
-            A p1 = gii[n] * ((A)D * (uv[n] * s2v[n]));
-            if constexpr (MEAN) p1 += gii[n] * ((A)D * (uv0[n] * s2v[n]));
-            grad_u[ro[n]] = (T)tu;
-            part_s2[ro[n]] = (T)ts;
-            part_s1[ro[n]] = (T)p1;
+    };
+
+    u32x4 raw[K];
+    A s1v[NACC];
+    Rows rw;
+    fetch_data(t, raw, s1v);
+    if constexpr (!PIPE) {
+        fetch_rows(t, rw);
+        A r[K][VEC];
+        scale_in(raw, s1v, r);
+        transform(r);
+        sums_out(t, rw, r);
+    } else {
+        for (;;) {
+            A r[K][VEC];
+            scale_in(raw, s1v, r);
+            fetch_rows(t, rw);
+            const int64_t tn = t + stride;
+            if (tn < n_tiles) fetch_data(tn, raw, s1v);      // in flight while tile t is transformed and summed
+            transform(r);
+            sums_out(t, rw, r);
+            if (tn >= n_tiles) break;
+            t = tn;
         }
     }
 }
@@ -198,7 +244,7 @@ wbar_bwd_kernel(T *grad_u, T *part_s1, T *part_s2, const u32x4 *gw, const T *__r
 template <typename T, int LOG2D>
 inline void launch_wbar_bwd(void *grad_u, void *part_s1, void *part_s2, const void *gw, const void *s1,
                             const void *u, const void *s2, int64_t rows, int64_t S, int64_t R, bool mean, bool no_lds,
-                            hipStream_t st)
+                            bool no_pipe, hipStream_t st)
 {
     constexpr int K = pick_k<T, LOG2D>();
     constexpr int VEC = Elem<T>::VEC;
@@ -206,25 +252,40 @@ inline void launch_wbar_bwd(void *grad_u, void *part_s1, void *part_s2, const vo
     const int64_t n_chunks = (rows << LOG2D) / VEC;
     const int64_t n_tiles = (n_chunks + 64 * K - 1) / (64 * K);
     const FastDiv dr = make_fastdiv((uint32_t)R), ds = make_fastdiv((uint32_t)S);
-    const unsigned grid = (unsigned)((n_tiles + 3) / 4);
+    const int64_t blocks = (n_tiles + 3) / 4;
     // the LDS-staged network needs 32-bit arithmetic and a 64-register tile; rows of at least 64 chunks make the
     // transposes worth it (below that few lane-bit stages exist and the DPP network is short)
     constexpr bool LDS_OK = sizeof(A) == 4 && K * VEC == 64 && LOG2D >= 8;
     constexpr size_t slab_bytes = (size_t)K * (64 * VEC + VEC) * 4;
-#define WHVI_BWD(NT, MEAN, POL)                                                                                  \
+    // rows of >= 2048 elements: at most two rows per tile, so the next tile's scalars fit the SGPR file next to the
+    // current one's (D = 512 / 1024 would spill: tools/check_spills.py)
+    constexpr bool PIPE_OK = LDS_OK && LOG2D >= 11;
+#define WHVI_BWD(NT, MEAN, POL, PIPE, GRID)                                                                      \
     do {                                                                                                         \
-        note_launch<T>("wbar_bwd_kernel", LOG2D, K, (bool)NT, (bool)MEAN, (int)POL);                             \
-        hipLaunchKernelGGL((wbar_bwd_kernel<T, LOG2D, K, NT, MEAN, POL>), dim3(grid), dim3(256),                 \
+        note_launch<T>("wbar_bwd_kernel", LOG2D, K, (bool)NT, (bool)MEAN, (int)POL, (bool)PIPE);                 \
+        hipLaunchKernelGGL((wbar_bwd_kernel<T, LOG2D, K, NT, MEAN, POL, PIPE>), dim3((unsigned)(GRID)), dim3(256), \
                            (POL == POLICY_LDS) ? 4 * slab_bytes : 0, st, (T *)grad_u, (T *)part_s1, (T *)part_s2, \
                            (const u32x4 *)gw, (const T *)s1, (const T *)u, (const T *)s2, n_chunks, n_tiles,     \
                            (uint32_t)rows, dr, ds);                                                              \
     } while (0)
-#define WHVI_BWD_POL(NT, MEAN)                                           \
-    do {                                                                 \
-        if constexpr (LDS_OK) {                                          \
-            if (!no_lds) { WHVI_BWD(NT, MEAN, POLICY_LDS); break; }      \
-        }                                                                \
-        WHVI_BWD(NT, MEAN, POLICY_DPP);                                  \
+    // pipelined persistent grid: 2 blocks per CU (what the 4 x 16.6 KB slabs of a block allow), once every wave has
+    // at least 2 tiles to walk
+    const int64_t persistent = (int64_t)num_cu() * 2;
+#define WHVI_BWD_POL(NT, MEAN)                                                             \
+    do {                                                                                   \
+        if constexpr (LDS_OK) {                                                            \
+            if (!no_lds) {                                                                 \
+                if constexpr (PIPE_OK) {                                                   \
+                    if (!no_pipe && blocks >= 2 * persistent) {                            \
+                        WHVI_BWD(NT, MEAN, POLICY_LDS, true, persistent);                  \
+                        break;                                                             \
+                    }                                                                      \
+                }                                                                          \
+                WHVI_BWD(NT, MEAN, POLICY_LDS, false, blocks);                             \
+                break;                                                                     \
+            }                                                                              \
+        }                                                                                  \
+        WHVI_BWD(NT, MEAN, POLICY_DPP, false, blocks);                                     \
     } while (0)
     const bool nt = n_chunks * 16 > NT_MIN_BYTES;      // a read-only stream: non-temporal beyond the Infinity Cache
     if (mean) { if (nt) WHVI_BWD_POL(true, true); else WHVI_BWD_POL(false, true); }
@@ -241,7 +302,7 @@ inline int wbar_bwd_dispatch(void *grad_u, void *part_s1, void *part_s2, const v
     constexpr int LV = ilog2(Elem<T>::VEC);
     g_err[0] = 0;
     if (J < 0 || S < 0 || R < 0) return fail(WHVI_ERR_ARG, "whvi_wbar_bwd: negative size%s", "");
-    if (flags & ~(WHVI_WBAR_MEAN | WHVI_WBAR_NO_LDS)) return fail(WHVI_ERR_ARG, "whvi_wbar_bwd: unknown flags%s 0x%llx", "", flags);
+    if (flags & ~(WHVI_WBAR_MEAN | WHVI_WBAR_NO_LDS | WHVI_WBAR_NO_PIPE)) return fail(WHVI_ERR_ARG, "whvi_wbar_bwd: unknown flags%s 0x%llx", "", flags);
     if (log2d < LV || log2d > max_single_pass_log2d<T>())
         return fail(WHVI_ERR_SIZE, "whvi_wbar_bwd: log2(D)%s = %lld is outside the supported range [%lld, ...]", "",
                     log2d, LV);
@@ -257,7 +318,7 @@ inline int wbar_bwd_dispatch(void *grad_u, void *part_s1, void *part_s2, const v
     case L:                                                                                                \
         if constexpr (L >= LV && L <= max_single_pass_log2d<T>())                                          \
             launch_wbar_bwd<T, L>(grad_u, part_s1, part_s2, gw, s1, u, s2, rows, S, R, (flags & WHVI_WBAR_MEAN) != 0,      \
-                                  (flags & WHVI_WBAR_NO_LDS) != 0, st);                 \
+                                  (flags & WHVI_WBAR_NO_LDS) != 0, (flags & WHVI_WBAR_NO_PIPE) != 0, st);                 \
         break;
     switch (log2d) {
         WHVI_CASE(1) WHVI_CASE(2) WHVI_CASE(3) WHVI_CASE(4) WHVI_CASE(5) WHVI_CASE(6) WHVI_CASE(7)
