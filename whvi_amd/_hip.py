@@ -16,7 +16,8 @@ import threading
 import torch  # noqa: F401  (must be loaded before the HIP library, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libwhvi_hip.so")
+# WHVI_HIP_LIB: path of an alternative build of the SAME library (tuning A/Bs, tools/); there is no other implementation
+LIB_PATH = os.environ.get("WHVI_HIP_LIB") or os.path.join(_HERE, "libwhvi_hip.so")
 
 AXIS_ROW, AXIS_COL = 0, 1
 F32, F64, F16, I32, BF16 = 0, 1, 2, 3, 4
@@ -338,7 +339,7 @@ def wbar_fwd(s1: torch.Tensor, u: torch.Tensor, s2: torch.Tensor, rows: int = No
 
 
 def wbar_bwd(grad_w: torch.Tensor, s1: torch.Tensor, u: torch.Tensor, s2: torch.Tensor, mean: bool = False,
-             no_lds: bool = False, no_pipe: bool = False):
+             no_lds: bool = False):
     """One launch: a (3, J, U, D) tensor [grad_u, part_s1, part_s2] from grad_w (J, S, R, D), s1 / s2 (J, D) and
     u (J, U, D), U = S -- or 1 + S with ``mean`` (W[j,k] = w_bar(u[j,0]) + w_bar(u[j,1+k]); slot 0 of the result is
     then left for the caller's sum over slots 1..S).  Entries i >= R are zero.  ``no_lds`` (tuning / cross-check):
@@ -357,7 +358,7 @@ def wbar_bwd(grad_w: torch.Tensor, s1: torch.Tensor, u: torch.Tensor, s2: torch.
     fn = getattr(lib(), "whvi_wbar_bwd_" + _DTYPE_SUFFIX[grad_w.dtype])
     with _OnDevice(grad_w.device):
         rc = fn(out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), grad_w.data_ptr(), s1.data_ptr(),
-                u.data_ptr(), s2.data_ptr(), J, S, R, D.bit_length() - 1, (1 if mean else 0) | (2 if no_lds else 0) | (4 if no_pipe else 0),
+                u.data_ptr(), s2.data_ptr(), J, S, R, D.bit_length() - 1, (1 if mean else 0) | (2 if no_lds else 0),
                 _stream(grad_w))
     _check(rc, "whvi_wbar_bwd")
     return out

@@ -183,11 +183,18 @@ __device__ __forceinline__ void bfly(A &lo, A &hi)
 // Two independent butterflies on adjacent registers as ONE v_pk_add_f32 pair (f32 only): halves
 // the issue slots of every in-register stage.  Same IEEE adds/subs, so the bits do not change.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+// -DWHVI_NO_PK (tuning builds): no explicit packed f32 instructions anywhere; combine with -fno-slp-vectorize so the
+// compiler forms none of its own either
+#ifdef WHVI_NO_PK
+constexpr bool kPackedF32 = false;
+#else
+constexpr bool kPackedF32 = true;
+#endif
 
 template <typename A, bool PK = true>
 __device__ __forceinline__ void bfly2(A &lo0, A &lo1, A &hi0, A &hi1)
 {
-    if constexpr (std::is_same<A, float>::value && PK) {
+    if constexpr (std::is_same<A, float>::value && PK && kPackedF32) {
         f32x2 a = {lo0, lo1}, b = {hi0, hi1};
         f32x2 s = a + b, d = a - b;
         lo0 = s[0];
@@ -205,7 +212,7 @@ __device__ __forceinline__ void bfly2(A &lo0, A &lo1, A &hi0, A &hi1)
 template <typename A>
 __device__ __forceinline__ void mul2(A &x0, A &x1, A m0, A m1)
 {
-    if constexpr (std::is_same<A, float>::value) {
+    if constexpr (std::is_same<A, float>::value && kPackedF32) {
         f32x2 x = {x0, x1}, m = {m0, m1};
         x = m * x;
         x0 = x[0];
@@ -218,7 +225,7 @@ __device__ __forceinline__ void mul2(A &x0, A &x1, A m0, A m1)
 template <typename A>
 __device__ __forceinline__ void add2(A &a0, A &a1, A x0, A x1)
 {
-    if constexpr (std::is_same<A, float>::value) {
+    if constexpr (std::is_same<A, float>::value && kPackedF32) {
         f32x2 a = {a0, a1}, x = {x0, x1};
         a = a + x;
         a0 = a[0];

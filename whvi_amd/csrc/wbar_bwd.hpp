@@ -18,26 +18,30 @@
 
 namespace whvi {
 
-// One xor-butterfly step of a wave all-reduce: every lane ends up with v(lane) + v(lane ^ (1 << LB)).  Lane bits 0..3
-// go through the DPP network, bits 4 / 5 through v_permlane16/32_swap on a copy (a' + b' holds the sum of the two
-// 16-lane rows / 32-lane halves in every lane) -- no ds_bpermute round trips through the LDS pipeline.
+// One lane-bit stage of the pruned butterfly: lanes whose bit LB is clear end up with v(lane) + sgn * v(lane ^ (1 << LB))
+// (the other lanes hold values nobody reads), sgn = +/-1 as a sign-bit mask.  Lane bits 0..3 go through the DPP
+// network, bits 4 / 5 through v_permlane16/32_swap on a copy -- no ds_bpermute round trips through the LDS pipeline.
 template <int LB, typename A>
-__device__ __forceinline__ A xor_reduce_step(A v)
+__device__ __forceinline__ A pruned_lane_step(A v, uint32_t sign_bit)
 {
     if constexpr (LB < 4) {
-        return v + Bits<A>::template partner_dpp<LB>(v);
+        const A t = Bits<A>::fold_sign(v, sign_bit);        // the partner reads +/- v
+        return v + Bits<A>::template partner_dpp<LB>(t);
     } else {
         A a = v, b = v;
-        swap_pair<(LB == 4) ? 16 : 32>(a, b);
-        return a + b;
+        swap_pair<(LB == 4) ? 16 : 32>(a, b);               // even rows / lower half: a' = own v, b' = the partner's v
+        return a + Bits<A>::fold_sign(b, sign_bit);
     }
 }
 
-template <typename A> __device__ __forceinline__ A sign_flip(A v, uint32_t sign_bit)    // sign_bit: 0 or 0x80000000
+// +1 or -1 (as A) from bit `bit` of i: the multiplier of the subtracted / added half at that butterfly stage
+template <typename A> __device__ __forceinline__ A stage_sign(uint32_t i, int bit)
 {
-    return Bits<A>::fold_sign(v, sign_bit);
+    return ((i >> bit) & 1u) ? (A)-1 : (A)1;
 }
-__device__ __forceinline__ uint32_t parity_sign(uint32_t x) { return (uint32_t)(__builtin_popcount(x) & 1) << 31; }
+// a + s * b with s = +/-1 exactly: one fused instruction, bit-identical to a + b / a - b (s * b is exact)
+__device__ __forceinline__ float pm_add(float a, float s, float b) { return __builtin_fmaf(b, s, a); }
+__device__ __forceinline__ double pm_add(double a, double s, double b) { return __builtin_fma(b, s, a); }
 
 // Tile ownership and index helpers as in fused_shs_kernel.  Rows are (J, S, R) x D, s1 / s2 are (J, D),
 // u is (J, S, D) -- or (J, 1 + S, D) with MEAN, row 0 of each j being the mean vector added to every sample's
@@ -49,16 +53,18 @@ __device__ __forceinline__ uint32_t parity_sign(uint32_t x) { return (uint32_t)(
 //     next to the tile loads -- wave-uniform (scalar loads) for rows of >= 64 chunks;
 //   * POLICY_LDS (f32, 64-register tiles): the six lane-bit stages of the transform run as packed in-register adds
 //     after one transpose through a private LDS slab (fwht_tile_lds: a third of the DPP network's issue slots);
-//   * the three signed row sums share one pass: the Hadamard sign (-1)^popcount(i & d) splits into an in-chunk part
-//     folded into the multipliers (+/- s2_i, +/- u_i, +/- u0_i per position: (-s) * g == -(s * g) exactly), a per-chunk
-//     part applied to the chunk's partial sums and a per-lane part applied once before the cross-lane reduction;
-//     products stay separate roundings (built with -ffp-contract=off), packed two per instruction;
-//   * cross-lane sums through DPP / permlane swaps (xor_reduce_step).
-//   * PIPE (LDS policy, big problems): the LDS slabs cap a CU at 8 waves, far fewer than its registers allow, so the
-//     spare registers hold the NEXT tile: a persistent grid (2 blocks per CU) walks the tiles with a grid stride and
-//     every wave issues tile t + stride's loads (data and row scalars) before it transforms tile t.
-template <typename T, int LOG2D, int K, bool NT, bool MEAN, int POLICY, bool PIPE>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE ? 2 : 1)))
+//   * the row sums share ONE signed sum: dL/du_i = sum_d g1[d] (H[i,d] s2_i) and dL/ds2_i = sum_d H[d,i] (u_i g1[d]) are
+//     s2_i * c and u_i * c with c = sum_d H[i,d] g1[d] = (H g1)[i], the common factor taken out of the sum (the op chain
+//     multiplies every term and then adds: same value up to the rounding of a D-term sum, whose order autograd leaves
+//     unspecified anyway).  c is ONE coefficient of a further transform of g1, i.e. a pruned butterfly: at the stage of
+//     index bit b keep a + b or a - b according to bit b of i -- D - 1 additions per row instead of 2-3 D multiplies
+//     and adds, written as fma(b, +/-1, a) (exact: the same bits as a +/- b) with the sign a wave-uniform scalar;
+//   * the lane-bit stages of that pruned butterfly run through DPP / permlane swaps (pruned_lane_step).
+// (Tried and dropped: a persistent grid of 2 blocks per CU whose waves prefetch tile t + stride into the registers the
+// LDS-limited occupancy leaves free -- 4.1-4.7 vs 4.4-4.9 TB/s at 1 GiB, 5.4 vs 5.6 at 4 GiB: the kernel was bound
+// by its VALU work, not by exposed load latency; tools/readbench.hip has the same comparison on a bare read stream.)
+template <typename T, int LOG2D, int K, bool NT, bool MEAN, int POLICY>
+__global__ void __launch_bounds__(256)
 wbar_bwd_kernel(T *grad_u, T *part_s1, T *part_s2, const u32x4 *gw, const T *__restrict__ s1, const T *__restrict__ u,
                 const T *__restrict__ s2, int64_t n_chunks, int64_t n_tiles, uint32_t n_rows, FastDiv by_r, FastDiv by_s)
 {
@@ -72,7 +78,6 @@ wbar_bwd_kernel(T *grad_u, T *part_s1, T *part_s2, const u32x4 *gw, const T *__r
     constexpr uint32_t CPR = 1u << SH;
     constexpr uint32_t D = 1u << LOG2D;
     static_assert(LOG2D >= LV, "rows of at least one chunk");
-    static_assert(!PIPE || SH >= 6, "the pipelined form keeps the next tile's row scalars in SGPRs: wave-uniform rows");
     // rows of one tile: SH >= 6 -> every row covers all 64 lanes and KPR = CPR/64 consecutive k;
     //                   SH <  6 -> every k holds 64/CPR rows side by side in the lanes
     constexpr int KPR = SH >= 6 ? (int)(CPR / 64) : 1;
@@ -82,10 +87,9 @@ wbar_bwd_kernel(T *grad_u, T *part_s1, T *part_s2, const u32x4 *gw, const T *__r
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int64_t blk = blockIdx.x;
-    if (NT && !PIPE && (gridDim.x & 7) == 0) blk = (blk & 7) * (int64_t)(gridDim.x >> 3) + (blk >> 3);   // XCD-contiguous
-    int64_t t = blk * 4 + wave;
+    if (NT && (gridDim.x & 7) == 0) blk = (blk & 7) * (int64_t)(gridDim.x >> 3) + (blk >> 3);   // XCD-contiguous
+    const int64_t t = blk * 4 + wave;
     if (t >= n_tiles) return;
-    const int64_t stride = (int64_t)gridDim.x * 4;
     const uint32_t lane_col = (uint32_t)lane & (CPR - 1);        // chunk column of this lane within its row (+ kk * 64)
 
     auto first_row = [&](int64_t tile, int k) -> uint32_t {
@@ -111,11 +115,15 @@ wbar_bwd_kernel(T *grad_u, T *part_s1, T *part_s2, const u32x4 *gw, const T *__r
     // the tile itself and the one scalar its first step needs
     auto fetch_data = [&](int64_t tile, u32x4 (&raw)[K], A (&s1v)[NACC]) {
         const int64_t base = tile * TILE;
-        const bool full = base + TILE <= n_chunks;
+        if (base + TILE <= n_chunks) {               // branch-free loads for full tiles
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            u32x4 z = {0u, 0u, 0u, 0u};
-            raw[k] = (full || base + k * 64 + lane < n_chunks) ? ld16<NT>(gw + base + k * 64 + lane) : z;
+            for (int k = 0; k < K; ++k) raw[k] = ld16<NT>(gw + base + k * 64 + lane);
+        } else {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                u32x4 z = {0u, 0u, 0u, 0u};
+                raw[k] = (base + k * 64 + lane < n_chunks) ? ld16<NT>(gw + base + k * 64 + lane) : z;
+            }
         }
 #pragma unroll
         for (int n = 0; n < NACC; ++n) {
@@ -156,61 +164,52 @@ wbar_bwd_kernel(T *grad_u, T *part_s1, T *part_s2, const u32x4 *gw, const T *__r
             fwht_tile<A, VEC, K, LOG2D, POLICY_DPP, 0>(r, lane);       // g1
         }
     };
-    // the row sums  dL/du = sum_d g1[d] * (H[i,d] s2_i)  and  dL/ds2 = sum_d H[d,i] * (u_i g1[d]) (+ u0_i g1[d]),
-    // H[i,d] = (-1)^popcount(i & d) with d = (kk * 64 + lane_col) * VEC + e; then one lane per row writes the results
+    // c = (H g1)[i] by a pruned butterfly over the row's elements d = (kk * 64 + lane_col) * VEC + e, then
+    // dL/du = s2_i c, dL/ds2 = u_i c (+ u0_i c); one lane per row writes the three results
     auto sums_out = [&](int64_t tile, const Rows &rw, A (&r)[K][VEC]) {
 #pragma unroll
         for (int n = 0; n < NACC; ++n) {
             const uint32_t i = rw.ri[n];
-            A m1[VEC], m2[VEC], m3[VEC];          // multipliers with the in-chunk sign folded in
+            // index bits [0, LV): positions inside a chunk
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                const uint32_t se = parity_sign(i & (uint32_t)e);
-                m1[e] = sign_flip(rw.s2v[n], se);
-                m2[e] = sign_flip(rw.uv[n], se);
-                m3[e] = sign_flip(rw.uv0[n], se);
-            }
-            A su[2] = {(A)0, (A)0}, ss[2] = {(A)0, (A)0};
+            for (int b = 0; b < LV; ++b) {
+                const A sg = stage_sign<A>(i, b);
 #pragma unroll
-            for (int kk = 0; kk < KPR; ++kk) {
-                const int k = n * KPR + kk;
-                A pu[2] = {(A)0, (A)0}, ps[2] = {(A)0, (A)0};
+                for (int kk = 0; kk < KPR; ++kk)
 #pragma unroll
-                for (int e = 0; e < VEC; e += 2) {
-                    A a0 = r[k][e], a1 = r[k][e + 1];
-                    mul2(a0, a1, m1[e], m1[e + 1]);                      // g * (+/- s2_i)
-                    add2(pu[0], pu[1], a0, a1);
-                    A b0 = r[k][e], b1 = r[k][e + 1];
-                    mul2(b0, b1, m2[e], m2[e + 1]);                      // (+/- u_i) * g
-                    add2(ps[0], ps[1], b0, b1);
-                    if constexpr (MEAN) {
-                        A c0 = r[k][e], c1 = r[k][e + 1];
-                        mul2(c0, c1, m3[e], m3[e + 1]);                  // (+/- u0_i) * g
-                        add2(ps[0], ps[1], c0, c1);
+                    for (int e = 0; e < VEC; e += 2 << b) {
+                        A &lo = r[n * KPR + kk][e];
+                        lo = pm_add(lo, sg, r[n * KPR + kk][e + (1 << b)]);
                     }
-                }
-                if constexpr (KPR > 1) {
-                    const uint32_t sk = parity_sign(i & ((uint32_t)kk * 64u * VEC));       // wave-uniform
-                    add2(su[0], su[1], sign_flip(pu[0], sk), sign_flip(pu[1], sk));
-                    add2(ss[0], ss[1], sign_flip(ps[0], sk), sign_flip(ps[1], sk));
-                } else {
-                    su[0] = pu[0]; su[1] = pu[1]; ss[0] = ps[0]; ss[1] = ps[1];
+            }
+            // index bits [LV + 6, LOG2D): the row's chunks held by this lane (rows of >= 64 chunks only)
+#pragma unroll
+            for (int b = 0; (1 << b) < KPR; ++b) {
+                const A sg = stage_sign<A>(i, LV + 6 + b);
+#pragma unroll
+                for (int kk = 0; kk < KPR; kk += 2 << b) {
+                    A &lo = r[n * KPR + kk][0];
+                    lo = pm_add(lo, sg, r[n * KPR + kk + (1 << b)][0]);
                 }
             }
-            const uint32_t sl = parity_sign(i & (lane_col * VEC));
-            A tu = sign_flip(su[0] + su[1], sl), ts = sign_flip(ss[0] + ss[1], sl);
+            // index bits [LV, LV + LANE_BITS): across the lanes that share the row
+            A c = r[n * KPR][0];
             static_for<0, LANE_BITS>([&](auto lb) {
-                tu = xor_reduce_step<decltype(lb)::value>(tu);
-                ts = xor_reduce_step<decltype(lb)::value>(ts);
+                constexpr int LB = decltype(lb)::value;
+                c = pruned_lane_step<LB>(c, ((i >> (LV + LB)) & 1u) << 31);
             });
             // outputs are laid out like u; entries i >= R stay untouched
             const uint32_t row = first_row(tile, n * KPR);
             const bool writer = (SH >= 6) ? (lane == 0) : (lane_col == 0);
             if (writer && row < n_rows) {
                 A p1 = rw.gii[n] * ((A)D * (rw.uv[n] * rw.s2v[n]));
-                if constexpr (MEAN) p1 += rw.gii[n] * ((A)D * (rw.uv0[n] * rw.s2v[n]));
-                grad_u[rw.ro[n]] = (T)tu;
-                part_s2[rw.ro[n]] = (T)ts;
+                A p2 = rw.uv[n] * c;
+                if constexpr (MEAN) {
+                    p1 += rw.gii[n] * ((A)D * (rw.uv0[n] * rw.s2v[n]));
+                    p2 += rw.uv0[n] * c;
+                }
+                grad_u[rw.ro[n]] = (T)(c * rw.s2v[n]);
+                part_s2[rw.ro[n]] = (T)p2;
                 part_s1[rw.ro[n]] = (T)p1;
             }
         }
@@ -220,31 +219,17 @@ wbar_bwd_kernel(T *grad_u, T *part_s1, T *part_s2, const u32x4 *gw, const T *__r
     A s1v[NACC];
     Rows rw;
     fetch_data(t, raw, s1v);
-    if constexpr (!PIPE) {
-        fetch_rows(t, rw);
-        A r[K][VEC];
-        scale_in(raw, s1v, r);
-        transform(r);
-        sums_out(t, rw, r);
-    } else {
-        for (;;) {
-            A r[K][VEC];
-            scale_in(raw, s1v, r);
-            fetch_rows(t, rw);
-            const int64_t tn = t + stride;
-            if (tn < n_tiles) fetch_data(tn, raw, s1v);      // in flight while tile t is transformed and summed
-            transform(r);
-            sums_out(t, rw, r);
-            if (tn >= n_tiles) break;
-            t = tn;
-        }
-    }
+    fetch_rows(t, rw);
+    A r[K][VEC];
+    scale_in(raw, s1v, r);
+    transform(r);
+    sums_out(t, rw, r);
 }
 
 template <typename T, int LOG2D>
 inline void launch_wbar_bwd(void *grad_u, void *part_s1, void *part_s2, const void *gw, const void *s1,
                             const void *u, const void *s2, int64_t rows, int64_t S, int64_t R, bool mean, bool no_lds,
-                            bool no_pipe, hipStream_t st)
+                            hipStream_t st)
 {
     constexpr int K = pick_k<T, LOG2D>();
     constexpr int VEC = Elem<T>::VEC;
@@ -257,35 +242,20 @@ inline void launch_wbar_bwd(void *grad_u, void *part_s1, void *part_s2, const vo
     // transposes worth it (below that few lane-bit stages exist and the DPP network is short)
     constexpr bool LDS_OK = sizeof(A) == 4 && K * VEC == 64 && LOG2D >= 8;
     constexpr size_t slab_bytes = (size_t)K * (64 * VEC + VEC) * 4;
-    // rows of >= 2048 elements: at most two rows per tile, so the next tile's scalars fit the SGPR file next to the
-    // current one's (D = 512 / 1024 would spill: tools/check_spills.py)
-    constexpr bool PIPE_OK = LDS_OK && LOG2D >= 11;
-#define WHVI_BWD(NT, MEAN, POL, PIPE, GRID)                                                                      \
+#define WHVI_BWD(NT, MEAN, POL)                                                                                  \
     do {                                                                                                         \
-        note_launch<T>("wbar_bwd_kernel", LOG2D, K, (bool)NT, (bool)MEAN, (int)POL, (bool)PIPE);                 \
-        hipLaunchKernelGGL((wbar_bwd_kernel<T, LOG2D, K, NT, MEAN, POL, PIPE>), dim3((unsigned)(GRID)), dim3(256), \
+        note_launch<T>("wbar_bwd_kernel", LOG2D, K, (bool)NT, (bool)MEAN, (int)POL);                             \
+        hipLaunchKernelGGL((wbar_bwd_kernel<T, LOG2D, K, NT, MEAN, POL>), dim3((unsigned)blocks), dim3(256),     \
                            (POL == POLICY_LDS) ? 4 * slab_bytes : 0, st, (T *)grad_u, (T *)part_s1, (T *)part_s2, \
                            (const u32x4 *)gw, (const T *)s1, (const T *)u, (const T *)s2, n_chunks, n_tiles,     \
                            (uint32_t)rows, dr, ds);                                                              \
     } while (0)
-    // pipelined persistent grid: 2 blocks per CU (what the 4 x 16.6 KB slabs of a block allow), once every wave has
-    // at least 2 tiles to walk
-    const int64_t persistent = (int64_t)num_cu() * 2;
-#define WHVI_BWD_POL(NT, MEAN)                                                             \
-    do {                                                                                   \
-        if constexpr (LDS_OK) {                                                            \
-            if (!no_lds) {                                                                 \
-                if constexpr (PIPE_OK) {                                                   \
-                    if (!no_pipe && blocks >= 2 * persistent) {                            \
-                        WHVI_BWD(NT, MEAN, POLICY_LDS, true, persistent);                  \
-                        break;                                                             \
-                    }                                                                      \
-                }                                                                          \
-                WHVI_BWD(NT, MEAN, POLICY_LDS, false, blocks);                             \
-                break;                                                                     \
-            }                                                                              \
-        }                                                                                  \
-        WHVI_BWD(NT, MEAN, POLICY_DPP, false, blocks);                                     \
+#define WHVI_BWD_POL(NT, MEAN)                                           \
+    do {                                                                 \
+        if constexpr (LDS_OK) {                                          \
+            if (!no_lds) { WHVI_BWD(NT, MEAN, POLICY_LDS); break; }      \
+        }                                                                \
+        WHVI_BWD(NT, MEAN, POLICY_DPP);                                  \
     } while (0)
     const bool nt = n_chunks * 16 > NT_MIN_BYTES;      // a read-only stream: non-temporal beyond the Infinity Cache
     if (mean) { if (nt) WHVI_BWD_POL(true, true); else WHVI_BWD_POL(false, true); }
@@ -302,7 +272,7 @@ inline int wbar_bwd_dispatch(void *grad_u, void *part_s1, void *part_s2, const v
     constexpr int LV = ilog2(Elem<T>::VEC);
     g_err[0] = 0;
     if (J < 0 || S < 0 || R < 0) return fail(WHVI_ERR_ARG, "whvi_wbar_bwd: negative size%s", "");
-    if (flags & ~(WHVI_WBAR_MEAN | WHVI_WBAR_NO_LDS | WHVI_WBAR_NO_PIPE)) return fail(WHVI_ERR_ARG, "whvi_wbar_bwd: unknown flags%s 0x%llx", "", flags);
+    if (flags & ~(WHVI_WBAR_MEAN | WHVI_WBAR_NO_LDS)) return fail(WHVI_ERR_ARG, "whvi_wbar_bwd: unknown flags%s 0x%llx", "", flags);
     if (log2d < LV || log2d > max_single_pass_log2d<T>())
         return fail(WHVI_ERR_SIZE, "whvi_wbar_bwd: log2(D)%s = %lld is outside the supported range [%lld, ...]", "",
                     log2d, LV);
@@ -318,7 +288,7 @@ inline int wbar_bwd_dispatch(void *grad_u, void *part_s1, void *part_s2, const v
     case L:                                                                                                \
         if constexpr (L >= LV && L <= max_single_pass_log2d<T>())                                          \
             launch_wbar_bwd<T, L>(grad_u, part_s1, part_s2, gw, s1, u, s2, rows, S, R, (flags & WHVI_WBAR_MEAN) != 0,      \
-                                  (flags & WHVI_WBAR_NO_LDS) != 0, (flags & WHVI_WBAR_NO_PIPE) != 0, st);                 \
+                                  (flags & WHVI_WBAR_NO_LDS) != 0, st);                 \
         break;
     switch (log2d) {
         WHVI_CASE(1) WHVI_CASE(2) WHVI_CASE(3) WHVI_CASE(4) WHVI_CASE(5) WHVI_CASE(6) WHVI_CASE(7)
