@@ -337,7 +337,7 @@ inline void launch_fused(void *dst, const void *src, const void *a, const void *
         hipLaunchKernelGGL((fused_shs_kernel<T, LOG2D, K, AX, EYE, NT, BLK, POL, STG>),                 \
                            dim3((unsigned)((n_tiles + (BLK / 64) - 1) / (BLK / 64))), dim3(BLK),        \
                            ((POL == POLICY_LDS) ? (size_t)(BLK / 64) * slab_bytes : 0) +                \
-                               ((STG) ? (size_t)8 << LOG2D : 0), st,                                    \
+                               ((STG) ? (2 * sizeof(typename Elem<T>::acc)) << LOG2D : 0), st,          \
                            (u32x4 *)dst, (const u32x4 *)src, (const T *)a, (const T *)b, (const T *)c,  \
                            n_chunks, n_tiles, ds, dn, dg, flags);                                       \
     } while (0)
@@ -363,6 +363,14 @@ inline void launch_fused(void *dst, const void *src, const void *a, const void *
     (void)t_pol; (void)t_nt; (void)t_stg;
 #define WHVI_FUSED_GEOM(AX, EYE)                                                                        \
     do {                                                                                                \
+        if constexpr (SMALL_TILE && AX == WHVI_AXIS_COL && !(EYE) && sizeof(T) == 8 &&                  \
+                      LOG2D >= 9 && LOG2D <= 12) {                                                      \
+            if (big && flags == 0) {     /* f64: shared a / c staged in LDS too (2 x 8 x D bytes) */    \
+                if (nt) WHVI_FUSED(AX, EYE, true, 256, POLICY_DPP, true);                               \
+                else WHVI_FUSED(AX, EYE, false, 256, POLICY_DPP, true);                                 \
+                break;                                                                                  \
+            }                                                                                           \
+        }                                                                                               \
         if constexpr (SMALL_TILE && AX == WHVI_AXIS_COL && !(EYE) && LDS_OK && sizeof(T) == 4 &&        \
                       LOG2D >= 9 && LOG2D <= 12) {                                                      \
             if (big && flags == 0) {                                                                    \

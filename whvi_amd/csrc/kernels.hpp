@@ -398,15 +398,15 @@ fused_shs_kernel(u32x4 *dst, const u32x4 *src, const T *a, const T *b, const T *
     // STAGE_AC (AXIS_COL, shared a and c): the block copies the two D-element vectors into LDS once;
     // every wave then reads its scale chunks from there instead of issuing 2 x K more global loads
     // through the L1 / texture path (the kernel's data stream already keeps that path busy).
-    constexpr int STAGED = STAGE_AC ? 2 * (1 << LOG2D) : 0;          // floats of LDS in front of the slabs
+    constexpr int STAGED = STAGE_AC ? 2 * (1 << LOG2D) : 0;          // elements of LDS in front of the slabs
     A *const lds_a = reinterpret_cast<A *>(whvi_smem);
     A *const lds_c = lds_a + (1 << LOG2D);
+    typedef A chunk_t __attribute__((ext_vector_type(VEC)));          // one 16-byte chunk of arithmetic values
     if constexpr (STAGE_AC) {
-        static_assert(AXIS == WHVI_AXIS_COL && !EYE && sizeof(A) == 4 && sizeof(T) == 4, "staging: f32 column scales");
-        typedef A vec4 __attribute__((ext_vector_type(4)));
-        for (int i = threadIdx.x * 4; i < (1 << LOG2D); i += BLOCK * 4) {
-            if (a != nullptr) *reinterpret_cast<vec4 *>(lds_a + i) = *reinterpret_cast<const vec4 *>(a + i);
-            if (c != nullptr) *reinterpret_cast<vec4 *>(lds_c + i) = *reinterpret_cast<const vec4 *>(c + i);
+        static_assert(AXIS == WHVI_AXIS_COL && !EYE && sizeof(A) == sizeof(T), "staging: f32 / f64 column scales");
+        for (int i = threadIdx.x * VEC; i < (1 << LOG2D); i += BLOCK * VEC) {
+            if (a != nullptr) *reinterpret_cast<chunk_t *>(lds_a + i) = *reinterpret_cast<const chunk_t *>(a + i);
+            if (c != nullptr) *reinterpret_cast<chunk_t *>(lds_c + i) = *reinterpret_cast<const chunk_t *>(c + i);
         }
         __syncthreads();
     }
@@ -448,34 +448,32 @@ fused_shs_kernel(u32x4 *dst, const u32x4 *src, const T *a, const T *b, const T *
         }
     };
 
-    // Issue order = latency plan: data + first scale vector together; the middle scale vector is
-    // requested BEFORE the first transform and the last one before the second, so their L2 round
-    // trips hide under ~1500 butterfly instructions each instead of stalling the wave three times.
     A r[K][VEC];
-    A sc[K][VEC];                      // the one scale vector in flight (AXIS_COL) / row scalars
-    auto fetch_scale = [&](const T *vec, bool per_sample) {
+
+    // shared a / c staged in LDS: multiply straight out of LDS, chunk by chunk -- no 64-register copy of a
+    // vector is ever live across a transform
+    auto apply_staged = [&](const A *staged) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const chunk_t v = *reinterpret_cast<const chunk_t *>(staged + chunk_col(k) * VEC);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) r[k][e] = v[e] * r[k][e];
+        }
+    };
+
+    // Scale vectors that are not staged in LDS (the per-sample vector b always; a / c when they are per-sample, f64,
+    // or the launch is small) are fetched from L2 where they are used -- AFTER the transform in front of them -- and consumed chunk by chunk
+    // (the scheduler keeps as many loads in flight as the register budget allows).  Requesting a whole vector before
+    // the transform to hide its latency -- the first design -- keeps 64 more registers live across ~1000 butterfly
+    // instructions: 184-202 VGPRs = 2 waves per SIMD instead of 3-4, which costs far more than the exposed round trip.
+    auto scale_chunkwise = [&](const T *vec, bool per_sample) {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             uint32_t vec_base = 0;
             if (per_sample)
                 vec_base = sample_index(chunk_row(k)) * (AXIS == WHVI_AXIS_COL ? (1u << LOG2D) : by_group_rows.d);
-            scale(vec, vec_base, k, sc[k]);
-        }
-    };
-    auto apply_scale = [&]() {
-#pragma unroll
-        for (int k = 0; k < K; ++k)
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) r[k][e] = sc[k][e] * r[k][e];
-    };
-
-    // shared a / c staged in LDS: multiply straight out of LDS, chunk by chunk -- no 64-register copy of the
-    // vector is ever live (the per-sample vector b is the only one held in registers across a transform)
-    auto apply_staged = [&](const A *staged) {
-        typedef A vec4 __attribute__((ext_vector_type(4)));
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const vec4 v = *reinterpret_cast<const vec4 *>(staged + chunk_col(k) * VEC);
+            A v[VEC];
+            scale(vec, vec_base, k, v);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) r[k][e] = v[e] * r[k][e];
         }
@@ -508,38 +506,46 @@ fused_shs_kernel(u32x4 *dst, const u32x4 *src, const T *a, const T *b, const T *
             for (int k = 0; k < K; ++k) E::unpack(raw[k], r[k]);
             if (c != nullptr) apply_staged(lds_c);
         } else {
-            if (c != nullptr) fetch_scale(c, c_per_sample);
 #pragma unroll
             for (int k = 0; k < K; ++k) E::unpack(raw[k], r[k]);
-            if (c != nullptr) apply_scale();
+            if (c != nullptr) scale_chunkwise(c, c_per_sample);     // its loads do not depend on the data: issued beside it
         }
     }
-    if constexpr (STAGE_AC) {
-        // per-sample vector: fetched from L2 after the first transform and consumed chunk by chunk (the
-        // scheduler keeps as many loads in flight as the 128-VGPR budget allows); holding all of it across the
-        // transform cost a whole wave of occupancy per SIMD
-        transform(r);
-        if (b != nullptr) {
+    // Tiles of more than 64 data registers (one f64 row of 4096 per wave) run at one wave per SIMD whatever is done
+    // here, so nothing but the wave itself can hide a scale vector's L2 round trip: there the vector IS requested
+    // before the transform in front of it (2.7 vs 2.4 TB/s).
+    constexpr bool AHEAD = (K * VEC * (int)sizeof(A) / 4 > 64) && !STAGE_AC;
+    A ahead[AHEAD ? K : 1][VEC];
+    auto fetch_ahead = [&](const T *vec, bool per_sample) {
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                A v[VEC];
-                scale(b, sample_index(chunk_row(k)) * (1u << LOG2D), k, v);
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) r[k][e] = v[e] * r[k][e];
-            }
+        for (int k = 0; k < (AHEAD ? K : 0); ++k) {
+            uint32_t vec_base = 0;
+            if (per_sample)
+                vec_base = sample_index(chunk_row(k)) * (AXIS == WHVI_AXIS_COL ? (1u << LOG2D) : by_group_rows.d);
+            scale(vec, vec_base, k, ahead[k]);
         }
+    };
+    auto apply_ahead = [&]() {
+#pragma unroll
+        for (int k = 0; k < (AHEAD ? K : 0); ++k)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) r[k][e] = ahead[k][e] * r[k][e];
+    };
+    if constexpr (AHEAD) {
+        if (b != nullptr) fetch_ahead(b, true);
+        transform(r);
+        if (b != nullptr) apply_ahead();
+        if (a != nullptr) fetch_ahead(a, a_per_sample);
+        transform(r);
+        if (a != nullptr) apply_ahead();
     } else {
-        if (b != nullptr) fetch_scale(b, true);
         transform(r);
-        if (b != nullptr) apply_scale();
-    }
-    if constexpr (STAGE_AC) {
+        if (b != nullptr) scale_chunkwise(b, true);
         transform(r);
-        if (a != nullptr) apply_staged(lds_a);
-    } else {
-        if (a != nullptr) fetch_scale(a, a_per_sample);
-        transform(r);
-        if (a != nullptr) apply_scale();
+        if (a != nullptr) {
+            if constexpr (STAGE_AC) apply_staged(lds_a);
+            else scale_chunkwise(a, a_per_sample);
+        }
     }
     if constexpr (NT) __syncthreads();          // the block's 4 waves write their 64 KiB back together
     if (NT && full) {
