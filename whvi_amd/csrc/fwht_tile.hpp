@@ -74,7 +74,11 @@ template <typename A> struct Bits;
 template <> struct Bits<float> {
     template <int LB> static __device__ __forceinline__ float partner_dpp(float v)
     {
-        return __builtin_bit_cast(float, dpp_xor_u32<LB>(__builtin_bit_cast(uint32_t, v)));
+        float p = __builtin_bit_cast(float, dpp_xor_u32<LB>(__builtin_bit_cast(uint32_t, v)));
+#ifdef WHVI_EXP_UNFUSED_DPP          // tuning builds: keep v_mov_b32_dpp apart from the add that consumes it (the i32 code shape)
+        asm volatile("" : "+v"(p));
+#endif
+        return p;
     }
     // upper lane of the pair computes partner - v, lower lane v + partner; folding the sign
     // into v first keeps it at one v_xor + one (DPP-fused) v_add.  p + (-v) == p - v exactly.
