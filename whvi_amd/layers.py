@@ -16,7 +16,7 @@ class WHVI:
         return 0.0
 
 
-def _choose_parameterisation(n_in, n_out, lambda_, bias):
+def _choose_parameterisation(n_in, n_out, lambda_, bias, mode="reference"):
     """Shape -> weight module, the rule of src/layers.py:31-38:
 
     =====================================  ==========================================
@@ -26,6 +26,13 @@ def _choose_parameterisation(n_in, n_out, lambda_, bias):
     anything else                          stack of square blocks of size 2^ceil(log2 n_in)
     =====================================  ==========================================
     """
+    if mode == "fastfood":
+        from whvi_amd.fastfood import WHVIFastfoodMatrix
+        if n_in != n_out or not is_pow_of_2(n_in):
+            raise ValueError("mode='fastfood' is implemented for square power-of-two layers")
+        return WHVIFastfoodMatrix(n_in, lambda_=lambda_, bias=bias)
+    if mode != "reference":
+        raise ValueError("mode must be 'reference' or 'fastfood'")
     if n_in == 1:
         return WHVIColumnMatrix(n_out, lambda_=lambda_, bias=bias)
     if n_out == 1:
@@ -39,11 +46,16 @@ class WHVILinear(nn.Module, WHVI):
     """Feed-forward layer whose weight matrix is a Walsh-Hadamard variational factorisation.
 
     ``lambda_`` is the prior variance; ``bias`` adds a plain (non-variational) bias.  The parameterisation
-    lives in ``self.weight_submodule`` -- that attribute name is part of the checkpoint format."""
+    lives in ``self.weight_submodule`` -- that attribute name is part of the checkpoint format.
 
-    def __init__(self, n_in, n_out, lambda_=1e-5, bias=False):
+    ``mode`` (keyword, not in the reference): ``"reference"`` (default) reproduces the reference as written;
+    ``"fastfood"`` opts in to the textbook operator S1 H diag(g) H S2 applied to activations without materialising W
+    (``whvi_amd.fastfood``) -- same parameters and KL, different (non-diagonal) weight matrix, square power-of-two
+    layers only."""
+
+    def __init__(self, n_in, n_out, lambda_=1e-5, bias=False, mode="reference"):
         super().__init__()
-        self.weight_submodule = _choose_parameterisation(n_in, n_out, lambda_, bias)
+        self.weight_submodule = _choose_parameterisation(n_in, n_out, lambda_, bias, mode)
 
     @property
     def kl(self):
