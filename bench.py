@@ -297,12 +297,13 @@ def _extra_sweep(device):
 def _extra_f16(device):
     """BASELINE config 5 (one GPU's share): D = 4096 fp16, 2^20 rows = 8 GiB."""
     from whvi_amd import _hip
-    x = (torch.randn(1 << 20, 4096, device=device) * 2.0 ** -8).half()
-    for _ in range(12):                       # clock ramp; these launches overflow fp16 (x 64 per transform) -- untimed
-        _hip.fwht_rows(x, out=x)
-    # fp16 spans 2^-24 .. 2^16: refill with small values so the timed in-place launches (x 2^6 each) stay in range
-    x.view(256, 4096, 4096).copy_(torch.randn(4096, 4096, device=device).mul_(2.0 ** -16).half())
-    res = _rate(1 << 20, 4096, 2, event_ms(lambda: _hip.fwht_rows(x, out=x), iters=4, warm=0))
+    x = torch.empty(1 << 20, 4096, device=device, dtype=torch.float16)
+    x.view(256, 4096, 4096).copy_((torch.randn(4096, 4096, device=device) * 2.0 ** -8).half())
+    # one in-place transform multiplies the data's magnitude by 64 and fp16 tops out at 65504: every launch is followed
+    # by an exact 2^-6 rescale (untimed: each transform has its own event pair).  Finite data matters for the number:
+    # on overflowed (inf / NaN) or all-zero data the same launch runs 1.5-2 % faster (tools/probe_f16_data.py: lower
+    # switching power, higher clock) -- round 1's 6.39 TB/s was measured on data that had overflowed.
+    res = _rate(1 << 20, 4096, 2, event_ms_each(lambda: _hip.fwht_rows(x, out=x), lambda i: x.mul_(2.0 ** -6), iters=12, warm=12))
     res.update(kernel=_hip.last_kernel(), values_finite=_finite(x))
     return res
 
