@@ -82,6 +82,17 @@ def test_argument_checks_of_the_training_step_entry_points():
     assert L.whvi_gauss_mnll_blocks(1) == 1 and L.whvi_gauss_mnll_blocks(10 ** 9) == 2048
 
 
+def test_last_kernel_before_any_launch():
+    """whvi_last_kernel: nothing launched in this (GPU-less) process -> empty string, length 0; bad buffers are refused."""
+    import ctypes
+    from whvi_amd import _hip
+    L = _hip.lib()
+    buf = ctypes.create_string_buffer(8)
+    assert L.whvi_last_kernel(buf, 8) == 0 and buf.value == b""
+    assert L.whvi_last_kernel(None, 8) == -1 and L.whvi_last_kernel(buf, 0) == -1
+    assert _hip.last_kernel() == ""
+
+
 def test_gpu_tensors_never_fall_back(monkeypatch):
     """A missing native library is an error, not a CPU detour."""
     from whvi_amd import _hip

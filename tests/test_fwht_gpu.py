@@ -265,3 +265,45 @@ def test_concurrent_host_threads(hip_lib):
     assert not errs, errs
     for i in range(4):
         assert torch.equal(outs[i], inputs[i] * float(d) ** 3)
+
+
+def test_last_kernel_names_the_launched_instantiation(hip_lib):
+    """whvi_last_kernel() reports the demangled symbol the dispatch selected (what bench.py prints as roofline.kernel):
+    the cached 256-thread launch for a small problem, the streaming one beyond the Infinity Cache, the fused kernel."""
+    x = torch.randn(64, 4096, device=DEV)
+    _hip.fwht_rows(x)
+    assert _hip.last_kernel() == "whvi::fwht_rows_kernel<float, 12, 16, 0, false, false, 256, 0>"
+    big = torch.zeros((1 << 29) // 2048 // 4 * 4, 2048, device=DEV)          # 512 MiB in place: streaming launch
+    _hip.fwht_rows(big, out=big)
+    assert _hip.last_kernel() == "whvi::fwht_rows_kernel<float, 11, 16, 0, false, true, 256, 1>"
+    h = torch.zeros(1 << 14, 4096, device=DEV, dtype=torch.float16)
+    _hip.fwht_rows(h, out=h)
+    assert _hip.last_kernel().startswith("whvi::fwht_rows_kernel<__half, 12, 8, ")
+    _hip.fused_shs(x, torch.ones(4096, device=DEV), None, None, axis="col")
+    assert _hip.last_kernel().startswith("whvi::fused_shs_kernel<float, 12, 16, 1, false, ")
+
+
+def test_bench_line_on_the_gpu(hip_lib):
+    """bench.py end to end at a small row count: one JSON line with the contract fields, the roofline object naming
+    the kernel that was launched, and a traffic value or an explicit reason why there is none for this shape."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--rows", "65536", "--steps", "3", "--warmup", "1",
+                          "--no-extras", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in rec, key
+    assert rec["n_gpus"] == 1 and rec["steps"] == 3 and rec["dtype"] == "f32" and rec["value"] > 0
+    roof = rec["roofline"]
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    assert roof["kernel"].startswith("whvi::fwht_rows_kernel<float, 12, 16, ")
+    assert roof["traffic"] is None and "no PMC record" in roof["traffic_note"]          # only the headline shape has one
+    assert rec["config"]["values_finite_after_run"] is True

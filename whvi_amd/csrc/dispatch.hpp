@@ -226,7 +226,17 @@ inline void launch_rows(void *dst, const void *src, int64_t n_chunks, int varian
 #define WHVI_LAUNCH_A(BLK, AL)                                                                             \
     hipLaunchKernelGGL((fwht_rows_kernel<T, LOG2D, K, POLICY_DPP, false, true, BLK, AL>),                  \
                        dim3((unsigned)((n_tiles + (BLK / 64) - 1) / (BLK / 64))), dim3(BLK), 0, st, d, s, n_chunks, n_tiles)
-            if (align == 0 || bpc > 0) {
+            if (align == 1 && bpc > 0 && blk == 0 && (n_tiles & 3) == 0) {
+                // persistent experiment: bpc blocks per CU walk the tiles with a grid stride, store barrier inside
+                // the loop (whole blocks share a trip count because n_tiles is a multiple of the 4 waves per block)
+                int64_t grid = (int64_t)num_cu() * bpc;
+                if (grid > n_tiles / 4) grid = n_tiles / 4;
+                grid &= ~(int64_t)7;                  // multiple of 8: the XCD-contiguous order stays a bijection
+                if (grid < 8) grid = 8;
+                note_launch<T>("fwht_rows_kernel", LOG2D, K, POLICY_DPP, false, true, 256, 1);
+                hipLaunchKernelGGL((fwht_rows_kernel<T, LOG2D, K, POLICY_DPP, false, true, 256, 1>), dim3((unsigned)grid),
+                                   dim3(256), 0, st, d, s, n_chunks, n_tiles);
+            } else if (align == 0 || bpc > 0) {
                 if (blk == 0) WHVI_LAUNCH(POLICY_DPP, false, true, 256);
                 else if (blk == 1) WHVI_LAUNCH(POLICY_DPP, false, true, 512);
                 else if (blk == 2) WHVI_LAUNCH(POLICY_DPP, false, true, 1024);
