@@ -139,17 +139,43 @@ def test_square_layer_matches_numpy_oracle_tightly(monkeypatch, hip_lib):
     assert np.abs(y - want).max() <= 2e-7 * scale
 
 
-def test_network_on_gpu_shapes_and_finite(hip_lib):
+def test_network_on_gpu_equals_host_path(monkeypatch, hip_lib):
+    """A 3 -> 64 -> 64 -> 1 network with all three layer flavours: loss, predictions and every gradient on the GPU
+    (fused kernels) against the host path (the reference's op chain under plain autograd) for the same parameters and
+    the same eps -- 1e-5 relative on values, 3e-5 on gradients (the host's dense-H matmul carries its own rounding)."""
+    import copy
     import torch.nn as nn
     from whvi_amd.networks import WHVIRegression
-    net = WHVIRegression([WHVILinear(3, 64), nn.ReLU(), WHVILinear(64, 64), nn.ReLU(), WHVILinear(64, 1)],
-                         train_samples=2, eval_samples=3).to(DEV)
-    x, y = torch.randn(17, 3, device=DEV), torch.randn(17, 1, device=DEV)
-    loss = net.loss(x, y, 100)
-    loss.backward()
-    assert torch.isfinite(loss) and all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
-    net.eval()
-    assert net(x).shape == (17, 1, 3)
+    from test_host import EpsRouter
+    torch.manual_seed(21)
+    S = 2
+    host = WHVIRegression([WHVILinear(3, 64, bias=True), nn.ReLU(), WHVILinear(64, 64), nn.ReLU(), WHVILinear(64, 1)],
+                          train_samples=S, eval_samples=3)
+    with torch.no_grad():
+        for n_, p_ in host.named_parameters():
+            if n_.endswith("g_mu") or n_.endswith("s1") or n_.endswith("s2"):
+                p_.copy_(torch.randn(p_.shape) * 0.3)
+    dev = copy.deepcopy(host).to(DEV)
+    g = torch.Generator().manual_seed(5)
+    # one table per layer WIDTH: the stacked layer has 16 sub-matrices of D = 4, square and column layers share D = 64
+    # but draw in a fixed order (square first), which EpsRouter's per-D call counter follows
+    tables = {4: torch.randn(S, 16, 4, generator=g), 64: torch.randn(2 * S, 1, 64, generator=g)}
+    x, y = torch.randn(17, 3, generator=g), torch.randn(17, 1, generator=g)
+    out = {}
+    real = torch.randn
+    for name, net, device in (("host", host, "cpu"), ("gpu", dev, DEV)):
+        net.mc_mode = "loop"
+        net.train()
+        monkeypatch.setattr(torch, "randn", EpsRouter({4: tables[4], 64: tables[64]}, "loop", real))
+        loss = net.loss(x.to(device), y.to(device), 100)
+        monkeypatch.undo()
+        loss.backward()
+        out[name] = (float(loss), torch.cat([p.grad.reshape(-1).cpu() for p in net.parameters()]))
+    assert abs(out["host"][0] - out["gpu"][0]) <= 1e-5 * abs(out["host"][0])
+    scale = float(out["host"][1].abs().max())
+    assert float((out["host"][1] - out["gpu"][1]).abs().max()) <= 3e-5 * scale
+    dev.eval()
+    assert dev(x.to(DEV)).shape == (17, 1, 3)
 
 
 def test_batched_mc_pass_equals_loop_gpu(monkeypatch, hip_lib):
@@ -226,15 +252,33 @@ def test_rows_shorter_than_a_chunk(dtype, hip_lib):
             assert np.array_equal(_bits(got[k * d:(k + 1) * d]), _bits(want))
 
 
-def test_tiny_layers_on_gpu(hip_lib):
-    """Shapes whose square blocks have D < 4: WHVILinear(2, 5) (stack of 2x2), (2, 2), (1, 1), (1, 3)."""
+def test_tiny_layers_on_gpu(monkeypatch, hip_lib):
+    """Shapes whose square blocks have D < 4 -- WHVILinear(2, 5) (stack of 2x2), (2, 2), (1, 1), (1, 3), (3, 1),
+    (2, 1): the batched pass (rows shorter than one 16-byte chunk take the thread-per-row kernels) equals one
+    stochastic pass per sample with the same eps; values against the oracle are in the next test."""
     for n_in, n_out in ((2, 5), (2, 2), (1, 1), (1, 3), (3, 1), (2, 1)):
+        torch.manual_seed(n_in * 7 + n_out)
         layer = WHVILinear(n_in, n_out, bias=True).to(DEV)
-        x = torch.randn(6, n_in, device=DEV, requires_grad=True)
-        y = layer(x)
-        (y.sum() + layer.kl).backward()
-        assert y.shape == (6, n_out) and torch.isfinite(y).all() and torch.isfinite(x.grad).all()
-        assert layer.forward_mc(x.detach(), 3).shape == (3, 6, n_out)
+        with torch.no_grad():
+            for n_, p_ in layer.named_parameters():
+                if n_.endswith("g_mu") or n_.endswith("s1") or n_.endswith("s2"):
+                    p_.copy_(torch.randn(p_.shape, device=DEV) * 0.5)
+        sub = layer.weight_submodule
+        J = getattr(sub, "stack", 1)
+        D = getattr(sub, "D_in", None) or getattr(sub, "D_adjusted", None) or sub.D
+        S = 3
+        eps = np.random.default_rng(n_in + 10 * n_out).standard_normal((S, J, D)).astype(np.float32)
+        x = torch.randn(6, n_in, device=DEV)
+        with torch.no_grad():
+            monkeypatch.setattr(torch, "randn", ReplayRandn([np.ascontiguousarray(np.swapaxes(eps, 0, 1))]))
+            batched = layer.forward_mc(x, S)
+            monkeypatch.undo()
+            for k in range(S):
+                monkeypatch.setattr(torch, "randn", ReplayRandn([eps[k, j] for j in range(J)]))
+                one = layer(x)
+                monkeypatch.undo()
+                assert one.shape == (6, n_out)
+                assert float((batched[k] - one).abs().max()) <= 1e-6 * max(float(one.abs().max()), 1e-20), (n_in, n_out, k)
 
 
 @pytest.mark.parametrize("n_in,n_out", [(2, 5), (2, 2), (1, 1), (1, 3), (3, 1), (2, 1), (5, 7), (7, 2), (16, 4),

@@ -62,6 +62,23 @@ def test_cpp_and_python_front_ends_bit_equal_to_reference(fg, d):
     assert torch.equal(x, torch.from_numpy(fg[f"f32_in_{d}"])), "input must not be modified"
 
 
+def test_config1_shape_on_the_host():
+    """BASELINE config 1 (benchmarks/walsh.py shape on the CPU: D = 512, batch 1024, fp32): the host library through the
+    reference's front-end classes, bit-equal to the oracle and -- where it is present -- to the reference's own compiled
+    C++ FWHT (oracle/_ref); integer data additionally satisfies H.H = 512.I exactly."""
+    import oracle
+    g = torch.Generator().manual_seed(512)
+    x = torch.randn(1024, 512, generator=g)
+    want = torch.from_numpy(oracle.fwht(x.numpy()))
+    for got in (cpp_fwht.FWHTFunction.apply(x), python_fwht.FWHTFunction.apply(x), fwht_cpp.forward(x)):
+        assert torch.equal(got, want)
+    ref = oracle.load_reference_cpp()
+    if ref is not None:
+        assert torch.equal(ref.forward(x), want)
+    xi = torch.randint(-8, 8, (1024, 512), generator=g, dtype=torch.int32)
+    assert torch.equal(fwht_cpp.forward(fwht_cpp.forward(xi)), xi * 512)
+
+
 def test_cpp_front_end_3d_input_like_benchmarks(fg):
     x = torch.from_numpy(fg["f32_in_3d"])     # benchmarks/walsh.py:21 feeds (1, D, D)
     assert torch.equal(fwht_cpp.forward(x), torch.from_numpy(fg["f32_out_3d"]))
