@@ -245,9 +245,80 @@ __device__ __forceinline__ void add2(A &a0, A &a1, A x0, A x1)
 // the issue slots of those stages but want even-aligned register pairs: in the plain streaming kernel that costs
 // 38 VGPRs (145 vs 107 = 3 vs 4 waves per SIMD) and 1.5 % of the stream at D = 4096, so it passes PK = false; the
 // fused / weight kernels (more VALU work per byte) are faster with it.
-template <typename A, int VEC, int K, int LOG2D, int POLICY, int PK = 7>
+//
+// SIGNED (f32 / f64, POLICY_DPP only): the DPP lane stages as ONE fused multiply-add per element instead of a sign fold
+// plus an add.  Every lane computes  own + s * partner  with s = +/-1 (exact: the same bits as own +/- partner), which is
+// the butterfly's result in the lower lane of a pair and its NEGATIVE in the upper lane; instead of repairing that, the
+// tile is allowed to hold sigma(lane) * value with sigma = (-1)^popcount(lane & mask): a stage on lane bit b uses
+// s = +1 / -1 for lower / upper lanes when the incoming mask has bit b clear (-1 / +1 when set) and toggles bit b of the
+// mask.  Everything else in the network is sign-agnostic per lane (in-register butterflies: (-a) +/- (-b) = -(a +/- b)
+// exactly; permlane swaps pair lanes with equal low four bits, i.e. equal sigma; elementwise scalings commute with it).
+// SIGN_IN is the mask the tile arrives with; fwht_sign_out() the one it leaves with.  Two transforms in a row (the fused
+// pipeline) toggle the same bits twice and end with mask 0: no repair at all.  Exact cancellations give +0 in either
+// convention, so results stay bit-identical for inputs without negative zeros.
+template <int VEC, int LOG2D>
+constexpr int fwht_sign_out(int sign_in)
+{
+    constexpr int LV = ilog2(VEC);
+    constexpr int NL = (LOG2D - LV) < 0 ? 0 : ((LOG2D - LV) > 4 ? 4 : (LOG2D - LV));      // DPP lane stages of this row length
+    return sign_in ^ ((1 << NL) - 1);
+}
+// x[i] += s * x[i](lane ^ (1 << LB)) for eight registers: v_fmac_f32_dpp reads the partner lane's value of its own
+// destination register.  A DPP instruction must not read a VGPR within two wait states of a VALU write to it and the
+// compiler's hazard recogniser cannot see into the block, so every block opens with s_nop 1 (covers whatever wrote the
+// eight registers just before) and touches eight DIFFERENT registers; lane ^ 4 needs two hops (row_half_mirror, then
+// quad_perm [3,2,1,0]) through temporaries written eight instructions before they are read.
+#define WHVI_FMAC_DPP8(CTRL)                                                                                   \
+    asm volatile("s_nop 1\n\t"                                                                                 \
+                 "v_fmac_f32_dpp %0, %0, %8 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                            \
+                 "v_fmac_f32_dpp %1, %1, %8 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                            \
+                 "v_fmac_f32_dpp %2, %2, %8 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                            \
+                 "v_fmac_f32_dpp %3, %3, %8 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                            \
+                 "v_fmac_f32_dpp %4, %4, %8 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                            \
+                 "v_fmac_f32_dpp %5, %5, %8 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                            \
+                 "v_fmac_f32_dpp %6, %6, %8 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                            \
+                 "v_fmac_f32_dpp %7, %7, %8 " CTRL " row_mask:0xf bank_mask:0xf"                                 \
+                 : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]) \
+                 : "v"(s))
+template <int LB>
+__device__ __forceinline__ void fmac_dpp8(float *x, float s)
+{
+    static_assert(LB >= 0 && LB <= 3, "DPP covers lane bits 0..3");
+    if constexpr (LB == 0) WHVI_FMAC_DPP8("quad_perm:[1,0,3,2]");
+    else if constexpr (LB == 1) WHVI_FMAC_DPP8("quad_perm:[2,3,0,1]");
+    else if constexpr (LB == 3) WHVI_FMAC_DPP8("row_ror:8");
+    else {
+        float t0, t1, t2, t3, t4, t5, t6, t7;
+        asm volatile("s_nop 1\n\t"
+                     "v_mov_b32_dpp %8, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                     "v_mov_b32_dpp %9, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                     "v_mov_b32_dpp %10, %2 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                     "v_mov_b32_dpp %11, %3 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                     "v_mov_b32_dpp %12, %4 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                     "v_mov_b32_dpp %13, %5 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                     "v_mov_b32_dpp %14, %6 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                     "v_mov_b32_dpp %15, %7 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f32_dpp %0, %8, %16 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f32_dpp %1, %9, %16 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f32_dpp %2, %10, %16 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f32_dpp %3, %11, %16 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f32_dpp %4, %12, %16 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f32_dpp %5, %13, %16 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f32_dpp %6, %14, %16 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f32_dpp %7, %15, %16 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf"
+                     : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]),
+                       "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
+                     : "v"(s));
+    }
+}
+#undef WHVI_FMAC_DPP8
+__device__ __forceinline__ float fma_pm(float p, float s, float v) { return __builtin_fmaf(p, s, v); }
+__device__ __forceinline__ double fma_pm(double p, double s, double v) { return __builtin_fma(p, s, v); }
+
+template <typename A, int VEC, int K, int LOG2D, int POLICY, int PK = 7, bool SIGNED = false, int SIGN_IN = 0>
 __device__ __forceinline__ void fwht_tile(A (&r)[K][VEC], const int lane)
 {
+    static_assert(!SIGNED || (POLICY == POLICY_DPP && !std::is_same<A, int32_t>::value), "signed form: f32 / f64 DPP network");
     constexpr int LV = ilog2(VEC);
     constexpr int LK = ilog2(K);
     static_assert(LOG2D <= LV + 6 + LK, "row does not fit the tile");
@@ -286,6 +357,22 @@ __device__ __forceinline__ void fwht_tile(A (&r)[K][VEC], const int lane)
                         A p = __shfl_xor(r[k][c], 1 << LB, 64);
                         r[k][c] = Bits<A>::combine(r[k][c], p, sign_mask, upper);
                     }
+            } else if constexpr (LB < 4 && SIGNED) {
+                // own + s * partner, s = -1 where this lane's bit LB differs from the incoming sign mask's bit LB ... see above
+                const A sgn = (upper != (bool)((SIGN_IN >> LB) & 1)) ? (A)-1 : (A)1;
+                if constexpr (std::is_same<A, float>::value && (K * VEC) % 8 == 0) {
+                    // v_fmac_f32_dpp, eight elements per block (the compiler fuses a DPP move into v_add_f32 but not into
+                    // an fma: VOP3 has no DPP form on gfx9 and the fmac shrink comes after its DPP combiner)
+                    float *flat = &r[0][0];
+#pragma unroll
+                    for (int g = 0; g < K * VEC; g += 8) fmac_dpp8<LB>(flat + g, sgn);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < K; ++k)
+#pragma unroll
+                        for (int c = 0; c < VEC; ++c)
+                            r[k][c] = fma_pm(Bits<A>::template partner_dpp<LB>(r[k][c]), sgn, r[k][c]);
+                }
             } else if constexpr (LB < 4) {
                 // A DPP instruction needs two wait states after a VALU write of ANY of its VGPR
                 // operands, so "v_xor t, mask, v; v_add_f32_dpp v, v, t" back to back costs an

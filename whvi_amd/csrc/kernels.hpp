@@ -415,12 +415,20 @@ fused_shs_kernel(u32x4 *dst, const u32x4 *src, const T *a, const T *b, const T *
         return;
     }
 
-    auto transform = [&](A (&r)[K][VEC]) {
+    // The two transforms of the pipeline use the signed DPP form (fwht_tile.hpp): the first leaves the tile with
+    // sigma = (-1)^popcount(lane & mask), the scalings between them commute with it, the second takes it back to 0.
+#ifndef WHVI_FUSED_SIGNED
+#define WHVI_FUSED_SIGNED 1
+#endif
+    constexpr bool SIGNED = WHVI_FUSED_SIGNED && POLICY == POLICY_DPP;
+    constexpr int SIGN_MID = SIGNED ? fwht_sign_out<VEC, LOG2D>(0) : 0;
+    static_assert(!SIGNED || fwht_sign_out<VEC, LOG2D>(SIGN_MID) == 0, "two transforms restore the sign convention");
+    auto transform = [&](A (&r)[K][VEC], auto second) {
         if constexpr (POLICY == POLICY_LDS)
             fwht_tile_lds<A, VEC, K, LOG2D>(r, lane, reinterpret_cast<A *>(whvi_smem) + STAGED +
                                                          wave * lds_slab_floats<VEC, K>());
         else
-            fwht_tile<A, VEC, K, LOG2D, POLICY_DPP, WHVI_FUSED_PKMASK>(r, lane);
+            fwht_tile<A, VEC, K, LOG2D, POLICY_DPP, WHVI_FUSED_PKMASK, SIGNED, decltype(second)::value ? SIGN_MID : 0>(r, lane);
     };
 
     const int64_t base = t * TILE;
@@ -533,15 +541,15 @@ fused_shs_kernel(u32x4 *dst, const u32x4 *src, const T *a, const T *b, const T *
     };
     if constexpr (AHEAD) {
         if (b != nullptr) fetch_ahead(b, true);
-        transform(r);
+        transform(r, IC<0>{});
         if (b != nullptr) apply_ahead();
         if (a != nullptr) fetch_ahead(a, a_per_sample);
-        transform(r);
+        transform(r, IC<1>{});
         if (a != nullptr) apply_ahead();
     } else {
-        transform(r);
+        transform(r, IC<0>{});
         if (b != nullptr) scale_chunkwise(b, true);
-        transform(r);
+        transform(r, IC<1>{});
         if (a != nullptr) {
             if constexpr (STAGE_AC) apply_staged(lds_a);
             else scale_chunkwise(a, a_per_sample);
