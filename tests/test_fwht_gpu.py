@@ -272,10 +272,10 @@ def test_last_kernel_names_the_launched_instantiation(hip_lib):
     the cached 256-thread launch for a small problem, the streaming one beyond the Infinity Cache, the fused kernel."""
     x = torch.randn(64, 4096, device=DEV)
     _hip.fwht_rows(x)
-    assert _hip.last_kernel() == "whvi::fwht_rows_kernel<float, 12, 16, 0, false, false, 256, 0>"
+    assert _hip.last_kernel() == "whvi::fwht_rows_kernel<float, 12, 16, 0, false, false, 256, 0, false>"
     big = torch.zeros((1 << 29) // 2048 // 4 * 4, 2048, device=DEV)          # 512 MiB in place: streaming launch
     _hip.fwht_rows(big, out=big)
-    assert _hip.last_kernel() == "whvi::fwht_rows_kernel<float, 11, 16, 0, false, true, 256, 1>"
+    assert _hip.last_kernel() == "whvi::fwht_rows_kernel<float, 11, 16, 0, false, true, 256, 1, true>"
     h = torch.zeros(1 << 14, 4096, device=DEV, dtype=torch.float16)
     _hip.fwht_rows(h, out=h)
     assert _hip.last_kernel().startswith("whvi::fwht_rows_kernel<__half, 12, 8, ")
@@ -307,3 +307,30 @@ def test_bench_line_on_the_gpu(hip_lib):
     assert roof["kernel"].startswith("whvi::fwht_rows_kernel<float, 12, 16, ")
     assert roof["traffic"] is None and "no PMC record" in roof["traffic_note"]          # only the headline shape has one
     assert rec["config"]["values_finite_after_run"] is True
+
+
+@pytest.mark.parametrize("log2d", [9, 10, 11])
+def test_signed_streaming_launch_of_f32_rows(log2d, hip_lib):
+    """f32 streams of D = 512 .. 2048 beyond the Infinity Cache take the SIGNED DPP network (one v_fmac_f32_dpp per
+    lane-stage element, the tile carrying (-1)^popcount(lane & 15) until one repair multiply at the end): 320 MiB in
+    place, random floats and small integers, sampled rows bit-identical to the oracle -- and to the unsigned network
+    (a cached out-of-place launch of the same rows) -- and H.H = D.I exactly on the integers."""
+    d = 1 << log2d
+    rows = (320 << 20) // (4 * d)
+    g = torch.Generator(device=DEV).manual_seed(log2d)
+    idx = torch.cat((torch.tensor([0, 1, 2, 3, rows // 2 + 1, rows - 2, rows - 1]), torch.randint(0, rows, (121,)))).to(DEV)
+    for kind in ("randn", "ints"):
+        if kind == "randn":
+            x = torch.randn(rows, d, device=DEV, generator=g)
+        else:
+            x = torch.randint(-3, 4, (rows, d), device=DEV, generator=g, dtype=torch.int32).float()
+        keep = x[idx].clone()
+        _hip.fwht_rows(x, out=x)
+        assert _hip.last_kernel() == f"whvi::fwht_rows_kernel<float, {log2d}, 16, 0, false, true, 256, 1, true>"
+        got = x[idx].cpu()
+        assert torch.equal(got.view(torch.int32), _oracle(keep.cpu()).view(torch.int32)), kind
+        small = _hip.fwht_rows(keep)                              # 128 rows: the cached, unsigned launch
+        assert _hip.last_kernel().endswith("256, 0, false>") and torch.equal(small.view(torch.int32), got.to(DEV).view(torch.int32))
+        if kind == "ints":
+            _hip.fwht_rows(x, out=x)
+            assert torch.equal(x[idx], keep * d) and torch.equal(x[::4099], x[::4099].round())

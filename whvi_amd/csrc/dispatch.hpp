@@ -145,7 +145,7 @@ inline void launch_rows(void *dst, const void *src, int64_t n_chunks, int varian
         int64_t grid = (n_tiles + (BLK / 64) - 1) / (BLK / 64);                                        \
         if (bpc > 0 && grid > (int64_t)num_cu() * bpc) grid = (int64_t)num_cu() * bpc;                 \
         const size_t smem = (POL == POLICY_LDS) ? (size_t)(BLK / 64) * rows_slab_bytes : 0;          \
-        note_launch<T>("fwht_rows_kernel", LOG2D, K, (int)POL, (bool)PF, (bool)NT, (int)BLK, 0);       \
+        note_launch<T>("fwht_rows_kernel", LOG2D, K, (int)POL, (bool)PF, (bool)NT, (int)BLK, 0, false); \
         hipLaunchKernelGGL((fwht_rows_kernel<T, LOG2D, K, POL, PF, NT, BLK>), dim3((unsigned)grid),    \
                            dim3(BLK), smem, st, d, s, n_chunks, n_tiles);                              \
     } while (0)
@@ -167,14 +167,16 @@ inline void launch_rows(void *dst, const void *src, int64_t n_chunks, int varian
                     // stream (6.1 TB/s).  The LDS-staged network needs a third of the issue slots: fp16 6.4,
                     // bf16 6.5 TB/s (tools/probe_f16.py), even at 8 waves per CU (16.6 KB of LDS per wave).
                 {
-                    note_launch<T>("fwht_rows_kernel", LOG2D, K, POLICY_LDS, false, true, 256, 1);
+                    note_launch<T>("fwht_rows_kernel", LOG2D, K, POLICY_LDS, false, true, 256, 1, false);
                     hipLaunchKernelGGL((fwht_rows_kernel<T, LOG2D, K, POLICY_LDS, false, true, 256, 1>),
                                        dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), (size_t)4 * rows_slab_bytes, st,
                                        d, s, n_chunks, n_tiles);
                 }
                 else {
-                    note_launch<T>("fwht_rows_kernel", LOG2D, K, POLICY_DPP, false, true, 256, 1);
-                    hipLaunchKernelGGL((fwht_rows_kernel<T, LOG2D, K, POLICY_DPP, false, true, 256, 1>),
+                    // f32 D = 512 .. 2048: the signed DPP network (+1.7 %, kernels.hpp); everything else unsigned
+                    constexpr bool SG = std::is_same<T, float>::value && LOG2D >= 9 && LOG2D <= 11;
+                    note_launch<T>("fwht_rows_kernel", LOG2D, K, POLICY_DPP, false, true, 256, 1, SG);
+                    hipLaunchKernelGGL((fwht_rows_kernel<T, LOG2D, K, POLICY_DPP, false, true, 256, 1, SG>),
                                        dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, st, d, s, n_chunks, n_tiles);
                 }
             } else if (big && sizeof(T) == 8) WHVI_LAUNCH(POLICY_DPP, false, false, BIG);
@@ -185,7 +187,7 @@ inline void launch_rows(void *dst, const void *src, int64_t n_chunks, int varian
             // tiles of more than 64 data VGPRs (one row per wave: f32 D = 8192, f64 D = 4096): 256-thread blocks
             // either way; streams get the non-temporal accesses and the store barrier as well
             if (big && nt) {
-                note_launch<T>("fwht_rows_kernel", LOG2D, K, POLICY_DPP, false, true, 256, 1);
+                note_launch<T>("fwht_rows_kernel", LOG2D, K, POLICY_DPP, false, true, 256, 1, false);
                 hipLaunchKernelGGL((fwht_rows_kernel<T, LOG2D, K, POLICY_DPP, false, true, 256, 1>),
                                    dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, st, d, s, n_chunks, n_tiles);
             } else WHVI_LAUNCH(POLICY_DPP, false, false, 256);
@@ -233,7 +235,7 @@ inline void launch_rows(void *dst, const void *src, int64_t n_chunks, int varian
                 if (grid > n_tiles / 4) grid = n_tiles / 4;
                 grid &= ~(int64_t)7;                  // multiple of 8: the XCD-contiguous order stays a bijection
                 if (grid < 8) grid = 8;
-                note_launch<T>("fwht_rows_kernel", LOG2D, K, POLICY_DPP, false, true, 256, 1);
+                note_launch<T>("fwht_rows_kernel", LOG2D, K, POLICY_DPP, false, true, 256, 1, false);
                 hipLaunchKernelGGL((fwht_rows_kernel<T, LOG2D, K, POLICY_DPP, false, true, 256, 1>), dim3((unsigned)grid),
                                    dim3(256), 0, st, d, s, n_chunks, n_tiles);
             } else if (align == 0 || bpc > 0) {

@@ -170,7 +170,7 @@ __device__ __forceinline__ void tile_store_stream(u32x4 *tile_base, int lane, in
 // dst/src: n_chunks 16-byte chunks; tile t = chunks [t*64*K, (t+1)*64*K).  Only the last tile
 // can be partial; its missing chunks belong to rows that do not exist (rows never straddle
 // tiles), so they are read as zero and never stored.
-template <typename T, int LOG2D, int K, int POLICY, bool PREFETCH, bool NT, int BLOCK = 256, int ALIGN = 0>
+template <typename T, int LOG2D, int K, int POLICY, bool PREFETCH, bool NT, int BLOCK = 256, int ALIGN = 0, bool SIGNED = false>
 #ifndef WHVI_ROWS_WAVES_PER_EU
 #define WHVI_ROWS_WAVES_PER_EU 1      // tuning hook (tools/probe_exp.py builds): minimum waves per SIMD to allocate for
 #endif
@@ -207,6 +207,22 @@ fwht_rows_kernel(u32x4 *dst, const u32x4 *src, int64_t n_chunks, int64_t n_tiles
 #ifndef WHVI_ROWS_PKMASK
 #define WHVI_ROWS_PKMASK 0
 #endif
+        // SIGNED (f32 streams of D = 512 .. 2048, chosen by the dispatch): the signed DPP stages of fwht_tile.hpp plus ONE
+        // repair multiply per element at the end, fma(r, sigma, +0): exact for every non-zero value, and an exact
+        // cancellation (+0 under either convention) stays +0.  Bit-identical to the unsigned network except that a
+        // NEGATIVE zero result (rows made of signed zeros only: -0 + -0) comes out as +0.  Measured 6.42-6.43 vs
+        // 6.30-6.33 TB/s at D = 512 / 1024 / 2048 (D = 4096: 6.0-6.4 vs 6.48, so that shape keeps the unsigned
+        // network); profiles/r02/plateau_*.
+        if constexpr (SIGNED) {
+            static_assert(POLICY == POLICY_DPP && std::is_same<A, float>::value, "signed form: f32 arithmetic, DPP network");
+            fwht_tile<A, VEC, K, LOG2D, POLICY_DPP, WHVI_ROWS_PKMASK, true, 0>(r, lane);
+            constexpr int OUT = fwht_sign_out<VEC, LOG2D>(0);
+            const A sg = (__builtin_popcount(lane & OUT) & 1) ? (A)-1 : (A)1;
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) r[k][c] = fma_pm(r[k][c], sg, (A)0);
+        } else
             fwht_tile<A, VEC, K, LOG2D, POLICY, WHVI_ROWS_PKMASK>(r, lane);      // no explicit packed adds here: see fwht_tile
     };
 
