@@ -12,3 +12,26 @@ def test_no_kernel_uses_scratch():
                          capture_output=True, text=True, timeout=1500)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert "0 with scratch" in out.stdout
+
+
+def test_roofline_traffic_is_tied_to_the_build(monkeypatch):
+    """bench.py reports the PMC-measured HBM traffic only for the kernel symbol AND the kernel sources it was collected
+    on (profiles/hbm_traffic.json carries both); anything else yields null with the reason."""
+    import json
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    rec = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))["fwht_f32_D4096_rows1048576"]
+    for field in ("hbm_bytes_per_launch", "kernel_symbol", "source_sha256", "algorithmic_bytes_per_launch"):
+        assert field in rec
+    assert 0.99 < rec["hbm_bytes_per_launch"] / rec["algorithmic_bytes_per_launch"] < 1.05
+    value, note = bench.recorded_traffic("fwht_f32_D4096_rows1048576", "whvi::some_other_kernel<float>")
+    assert value is None and "this run launched" in note
+    value, note = bench.recorded_traffic("fwht_f32_D512_rows7", rec["kernel_symbol"])
+    assert value is None and "no PMC record" in note
+    monkeypatch.setattr(bench, "kernel_source_hash", lambda: rec["source_sha256"])
+    value, note = bench.recorded_traffic("fwht_f32_D4096_rows1048576", rec["kernel_symbol"])
+    assert value == rec["hbm_bytes_per_launch"]
+    monkeypatch.setattr(bench, "kernel_source_hash", lambda: "0" * 64)
+    value, note = bench.recorded_traffic("fwht_f32_D4096_rows1048576", rec["kernel_symbol"])
+    assert value is None and "re-collect" in note
