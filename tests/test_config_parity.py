@@ -394,3 +394,33 @@ def test_config5_full_size_16bit_fwht_vs_oracle(dtype, hip_lib):
         _hip.fwht_rows(x, out=x)
         _hip.fwht_rows(x, out=x)
         assert torch.equal(x[tidx], keep * 4096)
+
+
+@pytest.mark.gpu
+def test_config4_full_size_share_vs_host_path(monkeypatch, hip_lib):
+    """BASELINE config 4 at one GPU's share of its timed size: the 3 -> 1024 -> 1024 -> 1 network, protein-sized batch
+    (45 730 rows), 16 of the 128 MC samples, batched predictive pass on the GPU.  64 sampled batch rows x all samples
+    against the host path (the reference's op chain) run on just those rows with the same parameters and eps; 1e-5."""
+    import copy
+    S, B = 16, 45730
+    g = _npz("config4_golden.npz")
+    host = _config4_net()
+    _load_flat(host, g["net/param_names"], g["net/params"])          # the reference-recorded (perturbed) parameters
+    host.eval()
+    dev = copy.deepcopy(host).to("cuda")
+    rng = np.random.default_rng(45730)
+    x = rng.standard_normal((B, 3)).astype(np.float32)
+    tables = [rng.standard_normal((S, 256, 4)).astype(np.float32), rng.standard_normal((S, 1, 1024)).astype(np.float32),
+              rng.standard_normal((S, 1, 1024)).astype(np.float32)]
+    monkeypatch.setattr(torch, "randn", BatchedReplay(tables))
+    with torch.no_grad():
+        pred = dev.forward_batched(torch.from_numpy(x).to("cuda"), S)             # (B, 1, S)
+    monkeypatch.undo()
+    assert pred.shape == (B, 1, S) and bool(torch.isfinite(pred).all())
+    rows = np.unique(np.concatenate([[0, 1, B - 1], rng.integers(0, B, 61)]))
+    monkeypatch.setattr(torch, "randn", BatchedReplay(tables))
+    with torch.no_grad():
+        want = host.forward_batched(torch.from_numpy(x[rows]), S)
+    monkeypatch.undo()
+    got = pred[torch.from_numpy(rows).to("cuda")].cpu()
+    assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())
