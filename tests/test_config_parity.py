@@ -424,3 +424,35 @@ def test_config4_full_size_share_vs_host_path(monkeypatch, hip_lib):
     monkeypatch.undo()
     got = pred[torch.from_numpy(rows).to("cuda")].cpu()
     assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mean", [False, True])
+def test_wbar_backward_at_streaming_size(mean, hip_lib):
+    """The backward of the weight construction at a size that takes the streaming launch (D = 2048 x 40 matrices =
+    640 MiB of dL/dW: non-temporal loads, the signed DPP network): every output against the float64 closed form the
+    as-written matrix implies (W = D diag(s1 u s2): dL/du_i = D s1_i s2_i gW_ii, ...) and bit-identical to the
+    LDS-staged network run on two of the matrices alone."""
+    from whvi_amd import _hip
+    D, S = 2048, 40
+    g = torch.Generator(device="cuda").manual_seed(7)
+    s1, s2 = torch.randn(1, D, device="cuda", generator=g), torch.randn(1, D, device="cuda", generator=g)
+    u = torch.randn(1, S + (1 if mean else 0), D, device="cuda", generator=g)
+    gw = torch.randn(1, S, D, D, device="cuda", generator=g)
+    out = _hip.wbar_bwd(gw, s1, u, s2, mean=mean)
+    assert _hip.last_kernel() == f"whvi::wbar_bwd_kernel<float, 11, 16, true, {'true' if mean else 'false'}, 0>"
+    first = 1 if mean else 0
+    diag = torch.diagonal(gw, dim1=2, dim2=3).double()                         # (1, S, D)
+    uk = u[:, first:].double()
+    want_u = D * s1.double().unsqueeze(1) * s2.double().unsqueeze(1) * diag
+    u_tot = uk + (u[:, :1].double() if mean else 0.0)
+    want_s2 = D * s1.double().unsqueeze(1) * u_tot * diag
+    want_s1 = D * u_tot * s2.double().unsqueeze(1) * diag
+    noise = 1e-6 * D * float(gw.abs().max()) * 8 * float(s1.abs().max() * s2.abs().max() * u.abs().max())
+    for got, want, name in ((out[0], want_u, "u"), (out[1], want_s1, "s1"), (out[2], want_s2, "s2")):
+        assert float((got[:, first:].double() - want).abs().max()) <= noise, name
+    k0 = 17
+    sub_u = torch.cat((u[:, :1], u[:, first + k0:first + k0 + 2]), dim=1) if mean else u[:, k0:k0 + 2]
+    small = _hip.wbar_bwd(gw[:, k0:k0 + 2].contiguous(), s1, sub_u.contiguous(), s2, mean=mean)
+    assert _hip.last_kernel().endswith(", 2>")                                # 32 MiB: the LDS-staged network
+    assert torch.equal(small[:, :, first:], out[:, :, first + k0:first + k0 + 2])

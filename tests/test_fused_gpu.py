@@ -481,8 +481,9 @@ def test_wbar_backward_kernel_vs_composed_chain(dtype, J, S, D, R, hip_lib):
         noise = (1e-6 if dtype == torch.float32 else 1e-14) * D * float(d64(gw).abs().max()) * 8
         assert float((got - w).abs().max()) <= noise * float(max(s1r.abs().max(), 1) * max(s2r.abs().max(), 1)
                                                              * max(ur.abs().max(), 1)), name
-    # the LDS-staged butterfly network (production for f32 rows of 256 .. 4096) and the DPP network make the same
-    # adds in the same order, and everything around them is shared: identical bits, with and without the mean term
+    # the LDS-staged butterfly network (f32 rows of 256 .. 4096, cache-resident sizes) and the DPP network in its signed
+    # form (streams) make the same adds in the same order up to exact sign flips, and everything around them is
+    # shared: identical values, with and without the mean term
     for mean in (False, True):
         uu = torch.cat((u[:, :1], u), dim=1) if mean else u
         a = _hip.wbar_bwd(gw, s1.detach(), uu.detach(), s2.detach(), mean=mean)

@@ -13,6 +13,7 @@ import torch
 from whvi_amd import _hip
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+no_lds = os.environ.get("WHVI_WBAR_NO_LDS") == "1"        # A/B: the DPP network instead of the LDS-staged one
 dev = torch.device("cuda", 0)
 for (J, S, D, mean) in ((1, 64, 2048, False), (1, 64, 2048, True), (1, 32, 512, True), (1, 16, 1024, True),
                         (256, 16, 4, True), (1, 8, 4096, True), (1, 256, 2048, False)):
@@ -21,16 +22,16 @@ for (J, S, D, mean) in ((1, 64, 2048, False), (1, 64, 2048, True), (1, 32, 512, 
     u = torch.randn(J, U, D, device=dev)
     gw = torch.randn(J, S, D, D, device=dev)
     for _ in range(5):
-        _hip.wbar_bwd(gw, s1, u, s2, mean=mean)
+        _hip.wbar_bwd(gw, s1, u, s2, mean=mean, no_lds=no_lds)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
-        _hip.wbar_bwd(gw, s1, u, s2, mean=mean)
+        _hip.wbar_bwd(gw, s1, u, s2, mean=mean, no_lds=no_lds)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     gb = gw.numel() * 4 / 1e9
-    print(f"wbar_bwd J={J} S={S} D={D} mean={int(mean)}: {ms:.4f} ms, {gb / ms * 1e3:.0f} GB/s of dL/dW "
+    print(f"{'dpp' if no_lds else 'lds'} wbar_bwd J={J} S={S} D={D} mean={int(mean)}: {ms:.4f} ms, {gb / ms * 1e3:.0f} GB/s of dL/dW "
           f"({gb * 1e3:.0f} MB) = {gb / ms / 8:.3f} of 8 TB/s", flush=True)
     del gw

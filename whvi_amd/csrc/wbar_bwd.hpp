@@ -51,8 +51,11 @@ __device__ __forceinline__ double pm_add(double a, double s, double b) { return 
 // 16 KiB tile cap a CU at 1.2 tiles / us = 5.0 TB/s for the chip -- profiles/r02/wbar_bwd_*):
 //   * every row's scalars (s1, u, u_mean, s2, the diagonal element of dL/dW, its indices) are fetched ONCE, up front,
 //     next to the tile loads -- wave-uniform (scalar loads) for rows of >= 64 chunks;
-//   * POLICY_LDS (f32, 64-register tiles): the six lane-bit stages of the transform run as packed in-register adds
-//     after one transpose through a private LDS slab (fwht_tile_lds: a third of the DPP network's issue slots);
+//   * two butterfly networks, chosen by size (launch_wbar_bwd): POLICY_LDS (f32, 64-register tiles, cache-resident
+//     gradients) runs the six lane-bit stages as in-register adds after one transpose through a private LDS slab
+//     (fwht_tile_lds: 704 add/sub per tile, 8 waves per CU); POLICY_DPP in its SIGNED form (f32, streams) keeps the
+//     DPP / permlane network with one v_fmac_f32_dpp per lane-stage element and 16 waves per CU -- the sign
+//     convention it leaves behind costs nothing here, it only flips bits of the row index in the pruned butterfly;
 //   * the row sums share ONE signed sum: dL/du_i = sum_d g1[d] (H[i,d] s2_i) and dL/ds2_i = sum_d H[d,i] (u_i g1[d]) are
 //     s2_i * c and u_i * c with c = sum_d H[i,d] g1[d] = (H g1)[i], the common factor taken out of the sum (the op chain
 //     multiplies every term and then adds: same value up to the rounding of a D-term sum, whose order autograd leaves
@@ -83,6 +86,11 @@ wbar_bwd_kernel(T *grad_u, T *part_s1, T *part_s2, const u32x4 *gw, const T *__r
     constexpr int KPR = SH >= 6 ? (int)(CPR / 64) : 1;
     constexpr int NACC = K / KPR;
     constexpr int LANE_BITS = SH >= 6 ? 6 : SH;
+    // DPP network in its signed form for f32 (fwht_tile.hpp): the transform leaves sigma(lane) * g1 with
+    // sigma = (-1)^popcount(lane & SIGN_OUT).  No repair is needed here: the pruned butterfly below multiplies lane l's
+    // partial sum by (-1)^popcount(i_lane & l) anyway, and sigma just flips the bits of i_lane under SIGN_OUT.
+    constexpr bool DPP_SIGNED = POLICY == POLICY_DPP && std::is_same<A, float>::value;
+    constexpr int SIGN_OUT = DPP_SIGNED ? fwht_sign_out<VEC, LOG2D>(0) : 0;
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -160,6 +168,8 @@ wbar_bwd_kernel(T *grad_u, T *part_s1, T *part_s2, const u32x4 *gw, const T *__r
         if constexpr (POLICY == POLICY_LDS) {
             extern __shared__ __attribute__((aligned(16))) char whvi_smem[];
             fwht_tile_lds<A, VEC, K, LOG2D>(r, lane, reinterpret_cast<A *>(whvi_smem) + wave * lds_slab_floats<VEC, K>());
+        } else if constexpr (DPP_SIGNED) {
+            fwht_tile<A, VEC, K, LOG2D, POLICY_DPP, 0, true, 0>(r, lane);       // g1, held as sigma(lane) * g1 (see SIGN_OUT)
         } else {
             fwht_tile<A, VEC, K, LOG2D, POLICY_DPP, 0>(r, lane);       // g1
         }
@@ -196,7 +206,7 @@ wbar_bwd_kernel(T *grad_u, T *part_s1, T *part_s2, const u32x4 *gw, const T *__r
             A c = r[n * KPR][0];
             static_for<0, LANE_BITS>([&](auto lb) {
                 constexpr int LB = decltype(lb)::value;
-                c = pruned_lane_step<LB>(c, ((i >> (LV + LB)) & 1u) << 31);
+                c = pruned_lane_step<LB>(c, (((i >> (LV + LB)) ^ (uint32_t)(SIGN_OUT >> LB)) & 1u) << 31);
             });
             // outputs are laid out like u; entries i >= R stay untouched
             const uint32_t row = first_row(tile, n * KPR);
@@ -250,10 +260,16 @@ inline void launch_wbar_bwd(void *grad_u, void *part_s1, void *part_s2, const vo
                            (const u32x4 *)gw, (const T *)s1, (const T *)u, (const T *)s2, n_chunks, n_tiles,     \
                            (uint32_t)rows, dr, ds);                                                              \
     } while (0)
+    // Which butterfly network (measured, profiles/r02/wbar_bwd_lds_vs_dpp.log): cache-resident gradients (<= 128 MiB)
+    // take the LDS-staged one (fewest instructions per wave: 10.0 vs 11.8 us at 32 MiB, 16.2 vs 17.4 at 64 MiB); streams
+    // take the DPP network in its signed form (1 050 VALU instructions per tile instead of 633 + 96 LDS, but 100 VGPRs
+    // and no LDS = 16 instead of 8 waves per CU): 6.3-6.4 vs 5.8-6.1 TB/s at 512 MiB, 5.3-6.0 vs 5.1-5.4 at 1 GiB,
+    // 6.56-6.62 vs 6.05-6.08 at 4 GiB.
+    const bool use_lds = !no_lds && n_chunks * 16 <= ((int64_t)128 << 20);
 #define WHVI_BWD_POL(NT, MEAN)                                           \
     do {                                                                 \
         if constexpr (LDS_OK) {                                          \
-            if (!no_lds) { WHVI_BWD(NT, MEAN, POLICY_LDS); break; }      \
+            if (use_lds) { WHVI_BWD(NT, MEAN, POLICY_LDS); break; }      \
         }                                                                \
         WHVI_BWD(NT, MEAN, POLICY_DPP);                                  \
     } while (0)
