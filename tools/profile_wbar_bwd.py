@@ -33,5 +33,5 @@ for (J, S, D, mean) in ((1, 64, 2048, False), (1, 64, 2048, True), (1, 32, 512, 
     ms = e0.elapsed_time(e1) / iters
     gb = gw.numel() * 4 / 1e9
     print(f"{'dpp' if no_lds else 'lds'} wbar_bwd J={J} S={S} D={D} mean={int(mean)}: {ms:.4f} ms, {gb / ms * 1e3:.0f} GB/s of dL/dW "
-          f"({gb * 1e3:.0f} MB) = {gb / ms / 8:.3f} of 8 TB/s", flush=True)
+          f"({gb * 1e3:.0f} MB) = {gb / ms / 8:.3f} of 8 TB/s  {_hip.last_kernel()[6:]}", flush=True)
     del gw
