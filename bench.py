@@ -252,9 +252,11 @@ def cpu_baseline(log2d, target_s=25.0):
         import fwht_cpp
         xs = torch.randn(1 << 15, d, generator=g)
         fwht_cpp.forward(xs[:1024])
-        t1 = time.perf_counter()
-        fwht_cpp.forward(xs)
-        dn = time.perf_counter() - t1
+        dn = float("inf")
+        for _ in range(3):                     # best of 3: the first call pays the page faults of a fresh 512 MiB result
+            t1 = time.perf_counter()
+            fwht_cpp.forward(xs)
+            dn = min(dn, time.perf_counter() - t1)
         if c1 is not None and "error" not in c1:
             fwht_cpp.forward(x1)
             t2 = time.perf_counter()
