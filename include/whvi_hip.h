@@ -197,6 +197,8 @@ int whvi_wbar_fwd_f64(void *dst, const void *s1, const void *u, const void *s2, 
 #define WHVI_WBAR_MEAN   1
 #define WHVI_WBAR_NO_LDS 2   /* tuning / cross-check: butterflies through the DPP network instead of the LDS-staged one
                               * (same adds in the same order: identical transform bits) */
+#define WHVI_WBAR_SMALL_TILES 4   /* tuning / cross-check: force the quarter-size tiles small problems take ... */
+#define WHVI_WBAR_BIG_TILES   8   /* ... or forbid them (default: chosen by size) */
 int whvi_wbar_bwd_f32(void *grad_u, void *part_s1, void *part_s2, const void *grad_w, const void *s1,
                       const void *u, const void *s2, int64_t J, int64_t S, int64_t R, int32_t log2d,
                       int32_t flags, void *stream);

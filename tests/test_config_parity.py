@@ -453,6 +453,10 @@ def test_wbar_backward_at_streaming_size(mean, hip_lib):
         assert float((got[:, first:].double() - want).abs().max()) <= noise, name
     k0 = 17
     sub_u = torch.cat((u[:, :1], u[:, first + k0:first + k0 + 2]), dim=1) if mean else u[:, k0:k0 + 2]
-    small = _hip.wbar_bwd(gw[:, k0:k0 + 2].contiguous(), s1, sub_u.contiguous(), s2, mean=mean)
-    assert _hip.last_kernel().endswith(", 2>")                                # 32 MiB: the LDS-staged network
-    assert torch.equal(small[:, :, first:], out[:, :, first + k0:first + k0 + 2])
+    gw2, u2 = gw[:, k0:k0 + 2].contiguous(), sub_u.contiguous()             # two of the matrices alone: 32 MiB
+    lds = _hip.wbar_bwd(gw2, s1, u2, s2, mean=mean, tiles="big")
+    assert _hip.last_kernel().endswith(", 16, false, " + ("true" if mean else "false") + ", 2>")      # LDS-staged network
+    assert torch.equal(lds[:, :, first:], out[:, :, first + k0:first + k0 + 2])
+    quarter = _hip.wbar_bwd(gw2, s1, u2, s2, mean=mean)                      # what a problem of this size takes by default
+    assert "wbar_bwd_kernel<float, 11, 8, false, " in _hip.last_kernel()     # quarter-size tiles, DPP network
+    assert torch.equal(quarter[:, :, first:], lds[:, :, first:])

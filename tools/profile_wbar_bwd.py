@@ -14,20 +14,28 @@ from whvi_amd import _hip
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 no_lds = os.environ.get("WHVI_WBAR_NO_LDS") == "1"        # A/B: the DPP network instead of the LDS-staged one
+tiles = os.environ.get("WHVI_WBAR_TILES")                 # A/B: "small" / "big" (default: chosen by size)
 dev = torch.device("cuda", 0)
-for (J, S, D, mean) in ((1, 64, 2048, False), (1, 64, 2048, True), (1, 32, 512, True), (1, 16, 1024, True),
-                        (256, 16, 4, True), (1, 8, 4096, True), (1, 256, 2048, False)):
+shapes = ((1, 64, 2048, False), (1, 64, 2048, True), (1, 32, 512, True), (1, 16, 1024, True), (256, 16, 4, True),
+          (1, 8, 4096, True), (1, 256, 2048, False))
+if os.environ.get("WHVI_WBAR_SMALL_SHAPES") == "1":       # the cache-resident shapes only (tile-size A/B)
+    shapes = ((1, 32, 512, True), (1, 16, 1024, True), (1, 4, 2048, True), (1, 128, 512, True), (1, 32, 1024, True),
+              (256, 16, 4, True), (3, 16, 64, True), (1, 8, 128, False))
+if os.environ.get("WHVI_WBAR_SMALL_SHAPES") == "2":       # around the tile-size crossover
+    shapes = ((1, 16, 2048, True), (1, 256, 512, True), (1, 64, 1024, True), (1, 8, 4096, True), (1, 32, 2048, True),
+              (1, 512, 512, True))
+for (J, S, D, mean) in shapes:
     U = S + 1 if mean else S
     s1, s2 = torch.randn(J, D, device=dev), torch.randn(J, D, device=dev)
     u = torch.randn(J, U, D, device=dev)
     gw = torch.randn(J, S, D, D, device=dev)
     for _ in range(5):
-        _hip.wbar_bwd(gw, s1, u, s2, mean=mean, no_lds=no_lds)
+        _hip.wbar_bwd(gw, s1, u, s2, mean=mean, no_lds=no_lds, tiles=tiles)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
-        _hip.wbar_bwd(gw, s1, u, s2, mean=mean, no_lds=no_lds)
+        _hip.wbar_bwd(gw, s1, u, s2, mean=mean, no_lds=no_lds, tiles=tiles)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters

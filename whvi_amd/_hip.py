@@ -339,11 +339,12 @@ def wbar_fwd(s1: torch.Tensor, u: torch.Tensor, s2: torch.Tensor, rows: int = No
 
 
 def wbar_bwd(grad_w: torch.Tensor, s1: torch.Tensor, u: torch.Tensor, s2: torch.Tensor, mean: bool = False,
-             no_lds: bool = False):
+             no_lds: bool = False, tiles: str = None):
     """One launch: a (3, J, U, D) tensor [grad_u, part_s1, part_s2] from grad_w (J, S, R, D), s1 / s2 (J, D) and
     u (J, U, D), U = S -- or 1 + S with ``mean`` (W[j,k] = w_bar(u[j,0]) + w_bar(u[j,1+k]); slot 0 of the result is
     then left for the caller's sum over slots 1..S).  Entries i >= R are zero.  ``no_lds`` (tuning / cross-check):
-    WHVI_WBAR_NO_LDS, the DPP butterfly network instead of the LDS-staged one.  See whvi_wbar_bwd_f32."""
+    WHVI_WBAR_NO_LDS, the DPP butterfly network instead of the LDS-staged one; ``tiles`` = "small" / "big" forces or
+    forbids the quarter-size tiles of small problems.  See whvi_wbar_bwd_f32."""
     if grad_w.device.type != "cuda" or grad_w.dtype not in (torch.float32, torch.float64):
         raise RuntimeError("wbar_bwd: float32 / float64 CUDA tensors only")
     J, S, R, D = grad_w.shape
@@ -358,7 +359,7 @@ def wbar_bwd(grad_w: torch.Tensor, s1: torch.Tensor, u: torch.Tensor, s2: torch.
     fn = getattr(lib(), "whvi_wbar_bwd_" + _DTYPE_SUFFIX[grad_w.dtype])
     with _OnDevice(grad_w.device):
         rc = fn(out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), grad_w.data_ptr(), s1.data_ptr(),
-                u.data_ptr(), s2.data_ptr(), J, S, R, D.bit_length() - 1, (1 if mean else 0) | (2 if no_lds else 0),
+                u.data_ptr(), s2.data_ptr(), J, S, R, D.bit_length() - 1, (1 if mean else 0) | (2 if no_lds else 0) | {None: 0, "small": 4, "big": 8}[tiles],
                 _stream(grad_w))
     _check(rc, "whvi_wbar_bwd")
     return out

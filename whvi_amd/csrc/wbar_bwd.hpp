@@ -239,12 +239,39 @@ wbar_bwd_kernel(T *grad_u, T *part_s1, T *part_s2, const u32x4 *gw, const T *__r
 template <typename T, int LOG2D>
 inline void launch_wbar_bwd(void *grad_u, void *part_s1, void *part_s2, const void *gw, const void *s1,
                             const void *u, const void *s2, int64_t rows, int64_t S, int64_t R, bool mean, bool no_lds,
-                            hipStream_t st)
+                            int small_tiles, hipStream_t st)
 {
     constexpr int K = pick_k<T, LOG2D>();
     constexpr int VEC = Elem<T>::VEC;
     using A = typename Elem<T>::acc;
     const int64_t n_chunks = (rows << LOG2D) / VEC;
+    // Cache-resident problems (<= the 256 MiB Infinity Cache): 16 KiB tiles give a CU only a handful of waves (config 2's
+    // backward, 32 MiB = 2 048 tiles = 8 waves per CU, each doing a whole tile's work back to back).  A quarter-size tile
+    // (never less than one row) makes four times the waves with a quarter of the work each.  DPP network (signed for
+    // f32), cached loads.  Kernel-trace medians, 16 KiB tiles (LDS-staged <= 128 MiB) -> quarter tiles
+    // (profiles/r02/wbar_bwd_tile_size.log): D = 4 x 256 matrices 5.8 -> 3.5 us, D = 512 x 32 (32 MiB) 9.7 -> 8.4,
+    // D = 1024 x 16 (64 MiB) 16.4 -> 14.7, D = 512 x 128 (128 MiB) 29.9 -> 22.8, 256 MiB 41-49 -> 41-44; at 512 MiB the
+    // two tie and the streaming launch below takes over.
+    constexpr int LVc = ilog2(VEC);
+    constexpr int NEED = (LOG2D > LVc + 6) ? (1 << (LOG2D - LVc - 6)) : 1;
+    constexpr int KS = NEED > 4 ? NEED : 4;
+    if constexpr (KS < K) {
+        const bool small = small_tiles > 0 || (small_tiles == 0 && n_chunks * 16 <= NT_MIN_BYTES);
+        if (small) {
+            const int64_t tiles_s = (n_chunks + 64 * KS - 1) / (64 * KS);
+            const FastDiv dr_s = make_fastdiv((uint32_t)R), ds_s = make_fastdiv((uint32_t)S);
+#define WHVI_BWD_SMALL(MEAN)                                                                                        \
+    do {                                                                                                            \
+        note_launch<T>("wbar_bwd_kernel", LOG2D, KS, false, (bool)MEAN, (int)POLICY_DPP);                           \
+        hipLaunchKernelGGL((wbar_bwd_kernel<T, LOG2D, KS, false, MEAN, POLICY_DPP>), dim3((unsigned)((tiles_s + 3) / 4)), \
+                           dim3(256), 0, st, (T *)grad_u, (T *)part_s1, (T *)part_s2, (const u32x4 *)gw, (const T *)s1, \
+                           (const T *)u, (const T *)s2, n_chunks, tiles_s, (uint32_t)rows, dr_s, ds_s);             \
+    } while (0)
+            if (mean) WHVI_BWD_SMALL(true); else WHVI_BWD_SMALL(false);
+#undef WHVI_BWD_SMALL
+            return;
+        }
+    }
     const int64_t n_tiles = (n_chunks + 64 * K - 1) / (64 * K);
     const FastDiv dr = make_fastdiv((uint32_t)R), ds = make_fastdiv((uint32_t)S);
     const int64_t blocks = (n_tiles + 3) / 4;
@@ -260,9 +287,9 @@ inline void launch_wbar_bwd(void *grad_u, void *part_s1, void *part_s2, const vo
                            (const u32x4 *)gw, (const T *)s1, (const T *)u, (const T *)s2, n_chunks, n_tiles,     \
                            (uint32_t)rows, dr, ds);                                                              \
     } while (0)
-    // Which butterfly network (measured, profiles/r02/wbar_bwd_lds_vs_dpp.log): cache-resident gradients (<= 128 MiB)
-    // take the LDS-staged one (fewest instructions per wave: 10.0 vs 11.8 us at 32 MiB, 16.2 vs 17.4 at 64 MiB); streams
-    // take the DPP network in its signed form (1 050 VALU instructions per tile instead of 633 + 96 LDS, but 100 VGPRs
+    // Which butterfly network for 16 KiB tiles (measured, profiles/r02/wbar_bwd_lds_vs_dpp.log): gradients of <= 128 MiB
+    // that are forced onto big tiles (WHVI_WBAR_BIG_TILES: cross-checks) take the LDS-staged one (fewest instructions
+    // per wave: 10.0 vs 11.8 us at 32 MiB, 16.2 vs 17.4 at 64 MiB); streams take the DPP network in its signed form (1 050 VALU instructions per tile instead of 633 + 96 LDS, but 100 VGPRs
     // and no LDS = 16 instead of 8 waves per CU): 6.3-6.4 vs 5.8-6.1 TB/s at 512 MiB, 5.3-6.0 vs 5.1-5.4 at 1 GiB,
     // 6.56-6.62 vs 6.05-6.08 at 4 GiB.
     const bool use_lds = !no_lds && n_chunks * 16 <= ((int64_t)128 << 20);
@@ -288,7 +315,7 @@ inline int wbar_bwd_dispatch(void *grad_u, void *part_s1, void *part_s2, const v
     constexpr int LV = ilog2(Elem<T>::VEC);
     g_err[0] = 0;
     if (J < 0 || S < 0 || R < 0) return fail(WHVI_ERR_ARG, "whvi_wbar_bwd: negative size%s", "");
-    if (flags & ~(WHVI_WBAR_MEAN | WHVI_WBAR_NO_LDS)) return fail(WHVI_ERR_ARG, "whvi_wbar_bwd: unknown flags%s 0x%llx", "", flags);
+    if (flags & ~(WHVI_WBAR_MEAN | WHVI_WBAR_NO_LDS | WHVI_WBAR_SMALL_TILES | WHVI_WBAR_BIG_TILES)) return fail(WHVI_ERR_ARG, "whvi_wbar_bwd: unknown flags%s 0x%llx", "", flags);
     if (log2d < LV || log2d > max_single_pass_log2d<T>())
         return fail(WHVI_ERR_SIZE, "whvi_wbar_bwd: log2(D)%s = %lld is outside the supported range [%lld, ...]", "",
                     log2d, LV);
@@ -304,7 +331,8 @@ inline int wbar_bwd_dispatch(void *grad_u, void *part_s1, void *part_s2, const v
     case L:                                                                                                \
         if constexpr (L >= LV && L <= max_single_pass_log2d<T>())                                          \
             launch_wbar_bwd<T, L>(grad_u, part_s1, part_s2, gw, s1, u, s2, rows, S, R, (flags & WHVI_WBAR_MEAN) != 0,      \
-                                  (flags & WHVI_WBAR_NO_LDS) != 0, st);                 \
+                                  (flags & WHVI_WBAR_NO_LDS) != 0,                                                       \
+                                  (flags & WHVI_WBAR_SMALL_TILES) ? 1 : ((flags & WHVI_WBAR_BIG_TILES) ? -1 : 0), st);                 \
         break;
     switch (log2d) {
         WHVI_CASE(1) WHVI_CASE(2) WHVI_CASE(3) WHVI_CASE(4) WHVI_CASE(5) WHVI_CASE(6) WHVI_CASE(7)
