@@ -19,7 +19,8 @@ namespace whvi {
 template <typename T, int LOG2D, int K, bool NT>
 __global__ void __launch_bounds__(256)
 wbar_fwd_kernel(u32x4 *dst, const T *s1, const T *u, const T *s2, const u32x4 *base, int64_t n_chunks,
-                int64_t n_tiles, uint32_t n_rows, FastDiv by_r, FastDiv by_s, uint32_t u_group, uint32_t u_first)
+                int64_t n_tiles, uint32_t n_rows, FastDiv by_r, FastDiv by_s, uint32_t u_group, uint32_t u_first,
+                uint32_t xcd_blocks, uint32_t n_mats)
 {
     using E = Elem<T>;
     using A = typename E::acc;
@@ -35,7 +36,20 @@ wbar_fwd_kernel(u32x4 *dst, const T *s1, const T *u, const T *s2, const u32x4 *b
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int64_t blk = blockIdx.x;
-    if (NT && (gridDim.x & 7) == 0) blk = (blk & 7) * (int64_t)(gridDim.x >> 3) + (blk >> 3);   // XCD-contiguous
+    if (xcd_blocks > 0) {
+        // with a mean matrix (`base`) every sample's matrix re-reads the same (J, R, D) values: give each XCD (blocks
+        // are dealt round-robin over the 8 XCDs) the SAME eighth of every matrix, so its 4 MiB L2 serves that eighth
+        // of `base` to all samples instead of each XCD pulling the whole matrix out of the Infinity Cache per sample.
+        // Within an XCD the MATRIX index runs fastest: consecutive blocks add the same 64 KiB of `base` to every sample,
+        // so the reuse distance is a few blocks whatever the matrix size (sample-major order re-reads an eighth of the
+        // matrix per sample: 8 MiB at D = 4096, twice the L2).
+        // xcd_blocks = blocks per matrix / 8 (host: only when that divides evenly; a bijection on the block index)
+        const uint32_t xcd = (uint32_t)blk & 7u, q = (uint32_t)(blk >> 3);
+        const uint32_t w = q / n_mats, m = q - w * n_mats;
+        blk = ((int64_t)m * 8 + xcd) * (int64_t)xcd_blocks + w;
+    } else if (NT && (gridDim.x & 7) == 0) {
+        blk = (blk & 7) * (int64_t)(gridDim.x >> 3) + (blk >> 3);   // XCD-contiguous
+    }
     const int64_t t = blk * 4 + wave;
     if (t >= n_tiles) {
         if constexpr (NT) __syncthreads();
@@ -101,10 +115,51 @@ inline void launch_wbar_fwd(void *dst, const void *s1, const void *u, const void
     const int64_t n_tiles = (n_chunks + 64 * K - 1) / (64 * K);
     const FastDiv dr = make_fastdiv((uint32_t)R), ds = make_fastdiv((uint32_t)S);
     const unsigned grid = (unsigned)((n_tiles + 3) / 4);
+    // Cache-resident results: quarter-size tiles (never less than one row), four times the waves with a quarter of the
+    // work each -- same reasoning and threshold as the backward kernel (wbar_bwd.hpp); WHVI_WBAR_FWD_TILES=big|small
+    // overrides (tuning, read once).
+    constexpr int LVc = ilog2(VEC);
+    constexpr int NEED = (LOG2D > LVc + 6) ? (1 << (LOG2D - LVc - 6)) : 1;
+    constexpr int KS = NEED > 4 ? NEED : 4;
+    // blocks per matrix / 8 when the XCD-sliced order applies (see the kernel): a mean matrix is added, every matrix
+    // is a whole number of 8 x 4-tile groups, and the grid is exactly the matrices' blocks
+    static const bool xcd_off = getenv("WHVI_WBAR_FWD_XCD") != nullptr && getenv("WHVI_WBAR_FWD_XCD")[0] == '0';   // A/B switch
+    const uint32_t n_mats = (uint32_t)(R > 0 ? rows / R : 0);
+    // (streaming launches only: 1 GiB of D = 2048 matrices 282 -> 194 us, 2 GiB 548 -> 323 = the rate without a mean
+    // matrix, D = 4096 x 16 297 -> 254; the cache-resident quarter-tile launches are faster in plain order -- 256 MiB:
+    // 48.6 vs 64.2 us; profiles/r02/wbar_fwd_tiles_and_order.log)
+    auto xcd_blocks_for = [&](int k, bool streaming) -> uint32_t {
+        const int64_t per_matrix = (R << LOG2D) / VEC, group = (int64_t)64 * k * 4 * 8;
+        if (!streaming || base == nullptr || xcd_off || per_matrix % group != 0 || n_chunks % per_matrix != 0) return 0u;
+        return (uint32_t)(per_matrix / group);
+    };
+    if constexpr (KS < K) {
+        static const char *tune = getenv("WHVI_WBAR_FWD_TILES");
+        const bool small = tune ? tune[0] == 's' : (n_chunks * 16 <= NT_MIN_BYTES);
+        const bool small_nt = tune && tune[0] == 's' && tune[1] == 'n' && n_chunks * 16 >= NT_MIN_BYTES;     // "sn": experiment
+        if (small) {
+            const int64_t tiles_s = (n_chunks + 64 * KS - 1) / (64 * KS);
+            if (small_nt) {
+                note_launch<T>("wbar_fwd_kernel", LOG2D, KS, true);
+                hipLaunchKernelGGL((wbar_fwd_kernel<T, LOG2D, KS, true>), dim3((unsigned)((tiles_s + 3) / 4)), dim3(256), 0, st,
+                                   (u32x4 *)dst, (const T *)s1, (const T *)u, (const T *)s2, (const u32x4 *)base, n_chunks,
+                                   tiles_s, (uint32_t)rows, dr, ds, (uint32_t)u_group, (uint32_t)u_first, xcd_blocks_for(KS, true), n_mats);
+                return;
+            }
+            note_launch<T>("wbar_fwd_kernel", LOG2D, KS, false);
+            hipLaunchKernelGGL((wbar_fwd_kernel<T, LOG2D, KS, false>), dim3((unsigned)((tiles_s + 3) / 4)), dim3(256), 0, st,
+                               (u32x4 *)dst, (const T *)s1, (const T *)u, (const T *)s2, (const u32x4 *)base, n_chunks,
+                               tiles_s, (uint32_t)rows, dr, ds, (uint32_t)u_group, (uint32_t)u_first, xcd_blocks_for(KS, false), n_mats);
+            return;
+        }
+    }
 #define WHVI_FWD(NT)                                                                                        \
-    hipLaunchKernelGGL((wbar_fwd_kernel<T, LOG2D, K, NT>), dim3(grid), dim3(256), 0, st, (u32x4 *)dst,       \
-                       (const T *)s1, (const T *)u, (const T *)s2, (const u32x4 *)base, n_chunks, n_tiles,  \
-                       (uint32_t)rows, dr, ds, (uint32_t)u_group, (uint32_t)u_first)
+    do {                                                                                                    \
+        note_launch<T>("wbar_fwd_kernel", LOG2D, K, (bool)NT);                                              \
+        hipLaunchKernelGGL((wbar_fwd_kernel<T, LOG2D, K, NT>), dim3(grid), dim3(256), 0, st, (u32x4 *)dst,   \
+                           (const T *)s1, (const T *)u, (const T *)s2, (const u32x4 *)base, n_chunks, n_tiles, \
+                           (uint32_t)rows, dr, ds, (uint32_t)u_group, (uint32_t)u_first, xcd_blocks_for(K, NT), n_mats); \
+    } while (0)
     if (n_chunks * 16 >= NT_MIN_BYTES) WHVI_FWD(true);
     else WHVI_FWD(false);
 #undef WHVI_FWD
