@@ -12,8 +12,9 @@
 //     dL/ds2[j,i]   += fwht(u_i * g1)[i] = sum_d H[d,i] * (u_i * g1[d])
 //     dL/ds1[j,i]   += sum_d gw[d] * fwht(u_i * t1)[d] = gw[i] * (D * (u_i * s2_i))
 //       (fwht(u_i s2_i H[i,:]) is exactly D u_i s2_i e_i: every partial sum is a power-of-two multiple or 0)
-// Every product is its own rounding, as in the separate ATen kernels; the two row sums run as an in-lane
-// sum followed by an xor-shuffle tree (autograd's own reduction order is unspecified as well).
+// The scaling in front of the transform and the final products are separate roundings, as in the separate ATen
+// kernels; the two row sums share one signed sum of g1 (a pruned butterfly, see below) -- autograd's own reduction
+// order is unspecified as well.
 #include "kernels.hpp"
 
 namespace whvi {
