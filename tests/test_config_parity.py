@@ -460,3 +460,29 @@ def test_wbar_backward_at_streaming_size(mean, hip_lib):
     quarter = _hip.wbar_bwd(gw2, s1, u2, s2, mean=mean)                      # what a problem of this size takes by default
     assert "wbar_bwd_kernel<float, 11, 8, false, " in _hip.last_kernel()     # quarter-size tiles, DPP network
     assert torch.equal(quarter[:, :, first:], lds[:, :, first:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,S", [(2048, 20), (512, 336), (4096, 6)])
+def test_weight_construction_at_streaming_size(D, S, hip_lib):
+    """The weight construction with the mean matrix added (the `forward_mc` form) at a size that takes the streaming
+    launch -- non-temporal stores, XCD-sliced / matrix-fastest block order (> 256 MiB of matrices): bit-identical to the
+    same matrices built one sample at a time (cache-resident launches, plain order), and equal to the closed form
+    D diag(s1 (u_mean + u_k) s2) within fp32 rounding."""
+    from whvi_amd import _hip
+    g = torch.Generator(device="cuda").manual_seed(D + S)
+    s1, s2 = torch.randn(1, D, device="cuda", generator=g), torch.randn(1, D, device="cuda", generator=g)
+    u = torch.randn(1, 1 + S, D, device="cuda", generator=g)
+    mean = _hip.wbar_fwd(s1, u, s2, D, first=0, count=1).view(1, D, D)
+    full = _hip.wbar_fwd(s1, u, s2, D, base=mean, first=1)                       # (1, S, D, D)
+    assert full.numel() * 4 > 256 << 20 and _hip.last_kernel().endswith(", 16, true>")
+    for k in (0, 1, S // 2, S - 1):
+        one = _hip.wbar_fwd(s1, u, s2, D, base=mean, first=1 + k, count=1)
+        assert _hip.last_kernel().endswith(", false>")
+        assert torch.equal(one[0, 0], full[0, k]), k
+    diag = torch.diagonal(full[0], dim1=1, dim2=2).double().cpu()                # (S, D)
+    want = D * s1[0].double().cpu() * (u[0, :1] + u[0, 1:]).double().cpu() * s2[0].double().cpu()
+    assert float((diag - want).abs().max()) <= 4e-6 * float(want.abs().max())
+    off = full[0, S - 1].clone()
+    off.diagonal().zero_()
+    assert float(off.abs().max()) == 0.0                                          # exactly diagonal (SURVEY finding 1)
