@@ -66,7 +66,7 @@ def test_argument_checks_of_the_training_step_entry_points():
     assert L.whvi_wbar_fwd_f32(p16, p16, p16, p16, None, 1, 2, 4, 2, 2, 1, None) == -1 and "u_group" in _hip.last_error()
     assert L.whvi_wbar_fwd_f32(None, None, None, None, None, 0, 3, 4, 2, 3, 0, None) == 0            # no matrices
     assert L.whvi_wbar_bwd_f32(p16, p16, p16, p16, p16, p16, p16, 1, 1, 4, 14, 0, None) == -2
-    assert L.whvi_wbar_bwd_f32(p16, p16, p16, p16, p16, p16, p16, 1, 1, 4, 2, 8, None) == -1 and "flags" in _hip.last_error()
+    assert L.whvi_wbar_bwd_f32(p16, p16, p16, p16, p16, p16, p16, 1, 1, 4, 2, 16, None) == -1 and "flags" in _hip.last_error()
     assert L.whvi_wbar_bwd_f64(p16, p16, p16, None, p16, p16, p16, 1, 1, 2, 1, 0, None) == -1
     assert L.whvi_wbar_bwd_f32(None, None, None, None, None, None, None, 2, 0, 4, 2, 1, None) == 0
     assert L.whvi_reparam_kl_bwd_f32(p16, p16, None, None, p16, p16, p16, p16, 1, 1, 4, 0.0, None) == -1   # lambda <= 0
