@@ -176,3 +176,32 @@ def test_config3_shape_through_the_module(monkeypatch, hip_lib):
     want = oracle.pipeline(x[idx % B], sub.s1.detach().cpu().numpy(), g[idx // B], sub.s2.detach().cpu().numpy(),
                            n_samples=len(idx), sample_stride=1, axis="col")
     assert np.array_equal(_bits(got), _bits(want))
+
+
+def run_small_widths(device, monkeypatch):
+    """Rows shorter than one 16-byte chunk (D = 1, 2) up to one chunk / one quad / one row of lanes: the same module,
+    bit-exact against the oracle."""
+    for D in (1, 2, 4, 8, 16, 64):
+        layer = _layer(D, seed=D, bias=False).to(device)
+        sub = layer.weight_submodule
+        rng = np.random.default_rng(D)
+        S, B = 3, 5
+        x = rng.standard_normal((B, D)).astype(np.float32)
+        eps = rng.standard_normal((S, D)).astype(np.float32)
+        monkeypatch.setattr(torch, "randn", ReplayRandn([eps]))
+        with torch.no_grad():
+            y = layer.forward_mc(torch.from_numpy(x).to(device), S).cpu().numpy()
+        monkeypatch.undo()
+        g = (sub.g_mu + sub.g_sigma * torch.from_numpy(eps).to(device)).detach().cpu().numpy()
+        want = oracle.pipeline(np.tile(x, (S, 1)), sub.s1.detach().cpu().numpy(), g, sub.s2.detach().cpu().numpy(),
+                               n_samples=S, sample_stride=B, axis="col").reshape(S, B, D)
+        assert np.array_equal(_bits(y), _bits(want)), D
+
+
+def test_small_widths_cpu(monkeypatch):
+    run_small_widths("cpu", monkeypatch)
+
+
+@pytest.mark.gpu
+def test_small_widths_gpu(monkeypatch, hip_lib):
+    run_small_widths("cuda", monkeypatch)
