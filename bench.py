@@ -333,6 +333,29 @@ def _extra_fused(device):
     return res
 
 
+def _extra_wbar_fwd(device):
+    """The weight construction (whvi_wbar_fwd, src/weights.py:73 and the mean + sample sum of :93): no HBM read, one write
+    of the matrices.  D = 2048 x 64 matrices (1 GiB) without and with the mean matrix (the `forward_mc` form, whose
+    16 MiB mean matrix is re-read by every sample: XCD-sliced block order), and config 2's weights (D = 512 x 32, 32 MiB)."""
+    from whvi_amd import _hip
+    out = {}
+    for key, (J, S, D, with_mean) in (("D2048_x64_1GiB", (1, 64, 2048, False)), ("D2048_x64_plus_mean_1GiB", (1, 64, 2048, True)),
+                                      ("D512_x32_plus_mean_config2", (1, 32, 512, True))):
+        s1, s2, u = torch.randn(J, D, device=device), torch.randn(J, D, device=device), torch.randn(J, 1 + S, D, device=device)
+        base = _hip.wbar_fwd(s1, u, s2, D, first=0, count=1).view(J, D, D) if with_mean else None
+        res = [None]
+
+        def run():
+            res[0] = _hip.wbar_fwd(s1, u, s2, D, base=base, first=1)
+        ms = event_ms(run, iters=20, warm=20)
+        gbs = J * S * D * D * 4 / (ms * 1e-3) / 1e9
+        out[key] = {"matrices": J * S, "D": D, "ms": round(ms, 4), "GB_per_s_written": round(gbs, 1),
+                    "frac_of_peak": round(gbs / HBM_PEAK_GBS, 4), "kernel": _hip.last_kernel(),
+                    "values_finite": bool(torch.isfinite(res[0][:, ::7]).all())}
+        res[0] = None
+    return out
+
+
 def _extra_wbar_bwd(device):
     """Backward of the weight construction (whvi_wbar_bwd, src/weights.py:73 under autograd): one launch reads dL/dW
     once.  D = 2048 x 64 matrices (1 GiB of gradient; the fused kernel's config-3 shape) and 4 GiB, and config 2's
@@ -480,7 +503,8 @@ def extras(device):
     recorded under its own key and never costs the other numbers or the headline line."""
     out = {}
     for key, fn in (("fwht_f32_sweep_4GiB", _extra_sweep), ("fwht_f16_D4096_2^20rows", _extra_f16),
-                    ("fused_shs_D2048_S64_B8192", _extra_fused), ("wbar_bwd", _extra_wbar_bwd),
+                    ("fused_shs_D2048_S64_B8192", _extra_fused), ("wbar_fwd", _extra_wbar_fwd),
+                    ("wbar_bwd", _extra_wbar_bwd),
                     ("whvilinear_512_fwd_kl_32mc_b4096", _extra_layer),
                     ("whviregression_3_1024_1024_1_mc16", _extra_network), ("toy_regression", _extra_toy)):
         try:
