@@ -333,6 +333,32 @@ def _extra_fused(device):
     return res
 
 
+def _extra_fastfood(device):
+    """The opt-in fastfood Module (WHVILinear(D, D, mode="fastfood"): the textbook S1.H.diag(g).H.S2 applied to activations
+    through ONE fused launch, config 3's kernel) beside the reference-equivalent layer of the same shape (S weight
+    matrices of D x D + a batched GEMM): D = 2048, 64 MC samples, batch 8192 -- config 3's shape -- forward only."""
+    from whvi_amd.layers import WHVILinear
+    D, S, B = 2048, 64, 8192
+    x = torch.randn(B, D, device=device)
+    out = {}
+    for mode in ("fastfood", "reference"):
+        layer = WHVILinear(D, D, mode=mode).to(device)
+        res = [None]
+
+        def run():
+            with torch.no_grad():
+                res[0] = layer.forward_mc(x, S)
+        ms = event_ms(run, iters=5, warm=3)
+        out[mode + "_ms"] = round(ms, 3)
+        out[mode + "_values_finite"] = _finite(res[0])
+        res[0] = None
+        del layer
+        torch.cuda.empty_cache()
+    out["note"] = ("fastfood = O(D log D) per row, no D x D weight (not reference-equivalent: the reference's weight is, as "
+                   "written, diagonal); reference = whvi_wbar_fwd for 64 matrices + one 4.4 TFLOP batched GEMM")
+    return out
+
+
 def _extra_wbar_fwd(device):
     """The weight construction (whvi_wbar_fwd, src/weights.py:73 and the mean + sample sum of :93): no HBM read, one write
     of the matrices.  D = 2048 x 64 matrices (1 GiB) without and with the mean matrix (the `forward_mc` form, whose
@@ -503,7 +529,8 @@ def extras(device):
     recorded under its own key and never costs the other numbers or the headline line."""
     out = {}
     for key, fn in (("fwht_f32_sweep_4GiB", _extra_sweep), ("fwht_f16_D4096_2^20rows", _extra_f16),
-                    ("fused_shs_D2048_S64_B8192", _extra_fused), ("wbar_fwd", _extra_wbar_fwd),
+                    ("fused_shs_D2048_S64_B8192", _extra_fused), ("fastfood_module_D2048_S64_B8192", _extra_fastfood),
+                    ("wbar_fwd", _extra_wbar_fwd),
                     ("wbar_bwd", _extra_wbar_bwd),
                     ("whvilinear_512_fwd_kl_32mc_b4096", _extra_layer),
                     ("whviregression_3_1024_1024_1_mc16", _extra_network), ("toy_regression", _extra_toy)):
