@@ -217,7 +217,8 @@ def run_train_trajectory(run, device, monkeypatch, tmp_path, mode, loss_rtol_fir
     net.mc_mode = mode
     X, Y = torch.from_numpy(g[f"{run}/X"]).to(device), torch.from_numpy(g[f"{run}/Y"]).to(device)
     loader = DataLoader(TensorDataset(X, Y), batch_size=8)
-    optimizer, scheduler = make_optimizer(net, **eval(str(g[f"{run}/optimizer_kwargs"])))
+    import ast
+    optimizer, scheduler = make_optimizer(net, **ast.literal_eval(str(g[f"{run}/optimizer_kwargs"])))
     epochs1, epochs2 = (int(v) for v in g[f"{run}/epochs"])
     steps = len(g[f"{run}/loss"])
     tables = [g[f"{run}/eps_layer{k}"] for k in range(3)]                 # (steps, S, J, D)
