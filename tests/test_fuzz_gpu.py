@@ -156,3 +156,12 @@ def test_random_weight_construction(case, dtype, J, S, D, R, mean, hip_lib):
         a = a.double().cpu()
         assert float((a[..., :R] - want[name]).abs().max()) <= bound, (case, name)
         assert R == D or float(a[..., R:].abs().max()) == 0.0
+    # every launch form of the backward kernel gives the same values: quarter-size tiles (what these sizes take by
+    # default), 16 KiB tiles with the LDS-staged network (f32 rows of 256 .. 4096) and with the DPP network
+    if _hip.wbar_bwd_supported(dtype, D):
+        dev = [t.detach() for t in p]
+        forms = [_hip.wbar_bwd(gw.to(DEV), dev[0], dev[1], dev[2], mean=mean, **kw)
+                 for kw in ({}, {"tiles": "big"}, {"tiles": "big", "no_lds": True}, {"tiles": "small"})]
+        first = 1 if mean else 0
+        for other in forms[1:]:
+            assert torch.equal(other[:, :, first:, :R], forms[0][:, :, first:, :R]), case
