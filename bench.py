@@ -581,11 +581,19 @@ def multi_gpu_extras(device, rank, world, small=False):
     except Exception as e:                      # noqa: BLE001
         err = repr(e)
     if _all_ok(x16 is not None, device):
-        for _ in range(10):
-            _hip.fwht_rows(x16, out=x16)
-        ms = _timed_all_ranks(lambda: _hip.fwht_rows(x16, out=x16), 10, device)
+        # finite data throughout: an exact 2^-6 rescale follows every transform (fp16 tops out at 65504 and an in-place
+        # transform multiplies the magnitude by 64); each transform has its own HIP-event pair, ranks start together
+        # behind a barrier, and the slowest rank's per-launch time is reported
+        rescale = lambda i: x16.mul_(2.0 ** -6)                                   # noqa: E731
+        event_ms_each(lambda: _hip.fwht_rows(x16, out=x16), rescale, iters=2, warm=10)
+        fence(device, world)
+        mine = event_ms_each(lambda: _hip.fwht_rows(x16, out=x16), rescale, iters=10, warm=0)
+        t = torch.tensor([mine], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ms = float(t.item())
         total = rows * world
         out["fwht_f16_D4096_2^20rows_row_sharded"] = {
+            "values_finite": _finite(x16), "kernel": _hip.last_kernel(),
             "rows_total": total, "rows_per_gpu": rows, "ms": round(ms, 4),
             "Gtransforms_per_s": round(total / ms / 1e6, 4), "GB_per_s_aggregate": round(total * 2 * 4096 * 2 / ms / 1e6, 1),
             "frac_of_aggregate_peak": round(total * 2 * 4096 * 2 / ms / 1e6 / (HBM_PEAK_GBS * world), 4),
