@@ -301,6 +301,25 @@ def _extra_sweep(device):
     return out
 
 
+def _extra_long_rows(device):
+    """Rows beyond one wavefront tile (outside the metric's D range): one block of 4 / 8 / 16 waves per row, one pass,
+    4 GiB in place; every launch is followed by an untimed rescale that brings the values back to where they started."""
+    from whvi_amd import _hip
+    out = {}
+    for dtype, log2d in ((torch.float32, 14), (torch.float32, 15), (torch.float32, 16), (torch.float64, 15), (torch.float16, 16)):
+        d, esize = 1 << log2d, torch.empty(0, dtype=dtype).element_size()
+        rows = (1 << 32) // (esize * d)
+        x = (torch.randn(rows, d, device=device) * 0.25).to(dtype)
+        ms = event_ms_each(lambda: _hip.fwht_rows(x, out=x),
+                           lambda i: x.mul_(2.0 ** (-(log2d // 2) - (i & 1) * (log2d & 1))), iters=8, warm=4)
+        key = f"{str(dtype)[6:]}_D={d}"
+        out[key] = _rate(rows, d, esize, ms)
+        out[key].update(kernel=_hip.last_kernel(), values_finite=_finite(x))
+        del x
+    out["note"] = "round 1 ran these as 4096-element pieces + high-bit passes at 3.0 TB/s (fp16: unsupported beyond D = 8192)"
+    return out
+
+
 def _extra_f16(device):
     """BASELINE config 5 (one GPU's share): D = 4096 fp16, 2^20 rows = 8 GiB."""
     from whvi_amd import _hip
@@ -528,7 +547,8 @@ def extras(device):
     """Secondary measurements (inputs resident, HIP-event timed).  Every section is independent: a failure is
     recorded under its own key and never costs the other numbers or the headline line."""
     out = {}
-    for key, fn in (("fwht_f32_sweep_4GiB", _extra_sweep), ("fwht_f16_D4096_2^20rows", _extra_f16),
+    for key, fn in (("fwht_f32_sweep_4GiB", _extra_sweep), ("fwht_long_rows_4GiB", _extra_long_rows),
+                    ("fwht_f16_D4096_2^20rows", _extra_f16),
                     ("fused_shs_D2048_S64_B8192", _extra_fused), ("fastfood_module_D2048_S64_B8192", _extra_fastfood),
                     ("wbar_fwd", _extra_wbar_fwd),
                     ("wbar_bwd", _extra_wbar_bwd),

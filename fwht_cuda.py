@@ -21,7 +21,7 @@ def fwht(X: torch.Tensor) -> torch.Tensor:
     Same contract as src/fwht/cuda/fwht_cuda.cpp:5-14: ``X`` must be a CUDA (HIP) tensor,
     two-dimensional, last dimension a power of two -- violations raise ``RuntimeError`` with
     the reference's messages; a NEW tensor is returned and ``X`` is left untouched.
-    Beyond the reference: float16 / bfloat16 / int32 inputs, D = 1, 2 and D up to 2^24 (16-bit types: 8192) work,
+    Beyond the reference: float16 / bfloat16 / int32 inputs, D = 1, 2 and D up to 2^24 (16-bit types: 65536) work,
     launch errors are raised instead of ignored, and the kernel runs on torch's current stream
     of ``X``'s device.
     """

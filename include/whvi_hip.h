@@ -68,9 +68,10 @@ int         whvi_last_kernel(char *buf, int32_t size);
                                              * returns its length, 0 before any launch.  Measurement aid: the
                                              * reference has no counterpart (its launcher picks between two kernels
                                              * silently, fwht_cuda_kernel.cu:156-181)                          */
-int         whvi_max_log2d(int32_t dtype);  /* largest supported log2(D): 24 for f32/f64/i32 (rows beyond
-                                             * 8192 / 4096 elements take extra high-bit passes), 13 for
-                                             * f16/bf16 (single pass only: one rounding)              */
+int         whvi_max_log2d(int32_t dtype);  /* largest supported log2(D): 24 for f32/f64/i32 (one pass up to
+                                             * D = 65536, f64 32768: a wave per row, then a block per row;
+                                             * longer rows take extra high-bit passes), 16 for f16/bf16
+                                             * (single pass only: one rounding)                        */
 
 /* Batched row FWHT: dst[r, :] = FWHT(src[r, :]) for r in [0, rows).
  * Replaces fwht_cuda_frontend (fwht_cuda_kernel.cu:156-181) + the X.clone() of

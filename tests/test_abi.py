@@ -49,7 +49,7 @@ def test_argument_checks_without_gpu():
     assert L.whvi_fwht_f32(None, None, 0, 3, None) == 0 and _hip.last_error() == ""   # empty batch
     assert L.whvi_fused_shs_f32(p16, p16, None, None, None, 1, 3, 0, 1, 1, 1, None) == -1  # n_samples < 1
     assert L.whvi_fused_shs_f32(p16, None, None, None, None, 1, 3, 1, 1, 9, 0, None) == -1  # identity needs group_rows <= D
-    assert [L.whvi_max_log2d(i) for i in range(5)] == [24, 24, 13, 24, 13] and L.whvi_max_log2d(7) == -1
+    assert [L.whvi_max_log2d(i) for i in range(5)] == [24, 24, 16, 24, 16] and L.whvi_max_log2d(7) == -1
 
 
 def test_argument_checks_of_the_training_step_entry_points():

@@ -37,9 +37,9 @@ def _oracle(x: torch.Tensor) -> torch.Tensor:
 @pytest.mark.parametrize("variant", [0, 1])
 def test_bit_exact_all_sizes(log2d, dtype, variant, hip_lib):
     if log2d > _hip.max_log2d(dtype):
-        pytest.skip("16-bit storage types are single-pass only")
+        pytest.skip("beyond the supported row length")
     if log2d > (12 if dtype == torch.float64 else 13) and variant != 0:
-        pytest.skip("beyond the single-wave row limit: only the production (multi-pass) launch applies")
+        pytest.skip("beyond the single-wave row limit: only the production (block-per-row) launch applies")
     d = 1 << log2d
     for rows in (1, 19, 67):   # odd batches like test/walsh.py:73; 67 rows -> a partial last tile
         x = _rand(rows, d, dtype, seed=1000 * log2d + rows)
@@ -212,13 +212,20 @@ def test_side_stream_and_autograd_thread(hip_lib):
     assert torch.equal(xr.grad, fwht_cuda.fwht(w))       # d/dx <w, xH> = wH (H symmetric)
 
 
-@pytest.mark.parametrize("dtype,log2d", [(torch.float32, 14), (torch.float32, 15), (torch.float32, 17), (torch.float32, 20),
-                                         (torch.float64, 13), (torch.float64, 16), (torch.int32, 16), (torch.int32, 19)])
+@pytest.mark.parametrize("dtype,log2d", [(torch.float32, 14), (torch.float32, 15), (torch.float32, 16), (torch.float32, 17),
+                                         (torch.float32, 20), (torch.float64, 13), (torch.float64, 14), (torch.float64, 15),
+                                         (torch.float64, 16), (torch.int32, 14), (torch.int32, 15), (torch.int32, 16),
+                                         (torch.int32, 19), (torch.float16, 14), (torch.float16, 15), (torch.float16, 16),
+                                         (torch.bfloat16, 14), (torch.bfloat16, 15), (torch.bfloat16, 16)])
 def test_rows_longer_than_one_wave(dtype, log2d, hip_lib):
-    """D beyond the register-resident limit (the reference's fwht_batch2 territory, dead code there): row kernel on
-    4096-element pieces + ascending high-bit passes; bit-exact vs the oracle, out of place and in place."""
+    """D beyond the register-resident limit (the reference's fwht_batch2 territory, dead code there): one block of
+    4 / 8 / 16 waves per row up to D = 65536 (f64: 32768), the bits above the wave tile through LDS; beyond that the
+    block kernel on 65536-element pieces + ascending high-bit passes.  Bit-exact vs the oracle, out of place and in
+    place; 16-bit storage keeps its single rounding (the oracle rounds once, from the f32 result)."""
     d = 1 << log2d
-    for rows in (1, 3):
+    for rows in (1, 3, 9):
+        if rows * d > (1 << 21):
+            continue
         x = _rand(rows, d, dtype, seed=77 + log2d + rows)
         want = _oracle(x)
         xd = x.to(DEV)
@@ -227,14 +234,40 @@ def test_rows_longer_than_one_wave(dtype, log2d, hip_lib):
         assert torch.equal(xd.cpu().view(torch.uint8), x.view(torch.uint8)), "input must stay untouched"
         _hip.fwht_rows(xd, out=xd)
         assert torch.equal(xd.cpu().view(torch.uint8), want.view(torch.uint8))
+    if log2d <= 16:
+        assert "fwht_block_rows_kernel" in _hip.last_kernel()
+
+
+@pytest.mark.parametrize("dtype,log2d", [(torch.float32, 14), (torch.float32, 16), (torch.float64, 15), (torch.float16, 16),
+                                         (torch.bfloat16, 15), (torch.int32, 15)])
+def test_block_rows_at_streaming_size(dtype, log2d, hip_lib):
+    """The same kernel in its streaming instantiation (non-temporal loads, write-through stores, XCD-contiguous block
+    order): 320 MiB in place, a row count that is not a multiple of 8 as well; sampled rows against the oracle, the
+    rest through the involution H(H(x)) = D x on exactly representable data."""
+    d = 1 << log2d
+    esize = torch.empty(0, dtype=dtype).element_size()
+    for rows in ((320 << 20) // (d * esize), (320 << 20) // (d * esize) + 3):
+        g = torch.Generator(device=DEV).manual_seed(5 + log2d)
+        x = torch.randint(-3, 4, (rows, d), device=DEV, generator=g, dtype=torch.int32).to(dtype)
+        keep = [0, 1, rows // 2, rows - 1]
+        want = _oracle(x[keep].cpu())
+        y = x.clone()
+        _hip.fwht_rows(y, out=y)
+        assert "fwht_block_rows_kernel" in _hip.last_kernel() and "true" in _hip.last_kernel()
+        assert torch.equal(y[keep].cpu().view(torch.uint8), want.view(torch.uint8)), (dtype, log2d, rows)
+        if dtype in (torch.float16, torch.bfloat16):
+            continue            # H x of +-3 integers needs more than 8 / 11 bits: no exact involution for 16-bit storage
+        _hip.fwht_rows(y, out=y)
+        assert torch.equal(y, x * d), (dtype, log2d, rows)
+        del y, x
 
 
 def test_half_types_reject_multi_pass_lengths(hip_lib):
     """fp16 / bf16 promise one rounding of the f32 result; a second pass would round the intermediate, so rows
-    beyond the single-wave limit are refused instead of silently losing bits."""
+    beyond the one-block limit (D = 65536) are refused instead of silently losing bits."""
     for dt in (torch.float16, torch.bfloat16):
         with pytest.raises(RuntimeError, match="outside the supported range"):
-            _hip.fwht_rows(torch.zeros(1, 1 << 14, dtype=dt, device=DEV))
+            _hip.fwht_rows(torch.zeros(1, 1 << 17, dtype=dt, device=DEV))
 
 
 def test_concurrent_host_threads(hip_lib):

@@ -56,9 +56,12 @@ constexpr int REPARAM_SAMPLES_PER_BLOCK = 8;
 // plus high-bit passes (fwht_high_kernel).
 template <typename T> constexpr int max_single_pass_log2d() { return sizeof(T) == 8 ? 12 : 13; }
 template <typename T> constexpr int multi_pass_low_log2d() { return sizeof(T) == 8 ? 11 : 12; }   // 64-VGPR tiles
+// One block per row (fwht_block_rows_kernel): 2 .. 16 wave tiles of 2^LOW elements, so rows up to 2^(LOW + 4) take
+// one pass as well: f32 / i32 / f16 / bf16 D <= 65536, f64 D <= 32768.
+template <typename T> constexpr int max_block_log2d() { return multi_pass_low_log2d<T>() + 4; }
 // 16-bit storage types stay single-pass: their contract is ONE rounding of the f32 result, and a pass boundary
 // would round the intermediate too.
-template <typename T> constexpr int max_log2d() { return sizeof(T) == 2 ? max_single_pass_log2d<T>() : 24; }
+template <typename T> constexpr int max_log2d() { return sizeof(T) == 2 ? max_block_log2d<T>() : 24; }
 
 // K = 16-byte chunks per lane: the smallest power of two that holds one row, but never below
 // the streaming size -- as many chunks as keep the tile at 64 data VGPRs (f32/i32/f64: 16 chunks =
@@ -266,6 +269,52 @@ inline void launch_rows(void *dst, const void *src, int64_t n_chunks, int varian
 #undef WHVI_LAUNCH
 }
 
+// One block of 2^LOG2W waves per row of 2^(LOW + LOG2W) elements (kernels.hpp: fwht_block_rows_kernel).
+template <typename T, int LOG2W>
+inline void launch_block_rows(void *dst, const void *src, int64_t n_rows, hipStream_t st)
+{
+    constexpr int W = 1 << LOG2W;
+    constexpr size_t smem = (size_t)W * 8 * 1024;
+    constexpr int LOW = multi_pass_low_log2d<T>();
+    const bool nt = stream_sized((n_rows << (LOW + LOG2W)) * (int64_t)sizeof(T), dst, src);
+#ifdef WHVI_BLOCK_TRACE
+    // probe builds: WHVI_BLOCK_TRACE=<device pointer, hex> receives 8 x uint64 per row (tools/probe_block_trace.py)
+    static const uintptr_t trace_env = [] { const char *e = getenv("WHVI_BLOCK_TRACE"); return e ? (uintptr_t)strtoull(e, nullptr, 16) : (uintptr_t)0; }();
+    uint64_t *trace = (uint64_t *)trace_env;
+#else
+    uint64_t *trace = nullptr;
+#endif
+    // Persistent, software-pipelined grid (kernels.hpp) once every resident block has several rows to walk; measured on
+    // 4 GiB in place (profiles/r02/long_rows_pipe_ab.log): 16-wave blocks f32 4.89 -> 5.95, i32 5.71 -> 6.01 TB/s; 4-wave
+    // blocks f32 5.68 -> 5.95, f64 5.71 -> 5.89; 8-wave blocks lose 2 % (two blocks per CU already overlap each other);
+    // 16-bit storage loses 20 % at 4 / 8 waves and gains nothing at 16 (half the bytes per butterfly: those rows are bound
+    // by the exchange, not by HBM), so it has no pipelined instantiations; neither has f64 at 16 waves, which needs 10
+    // registers more than a 1024-thread block has.  WHVI_BLOCK_PIPE=0 / 1 forces the choice where both forms exist (A/B).
+    static const int pipe_env = [] { const char *e = getenv("WHVI_BLOCK_PIPE"); return e ? atoi(e) : -1; }();
+    const int resident = num_cu() * (16 / W);                        // blocks the chip holds at once (16 waves per CU)
+    constexpr bool HAS_PIPE = sizeof(T) == 4 || (sizeof(T) == 8 && W < 16);
+    const bool pipe = HAS_PIPE && (pipe_env >= 0 ? (pipe_env != 0 && n_rows > resident) : (W != 8 && n_rows >= 4 * (int64_t)resident));
+    const int64_t grid = pipe ? resident : n_rows;                   // n_rows <= 2^31 - 1: far beyond any buffer
+    note_launch<T>("fwht_block_rows_kernel", LOG2W, nt, pipe);
+#define WHVI_BLOCK_ROWS(NTV, PIPEV)                                                                              \
+    do {                                                                                                         \
+        if constexpr (smem > 64 * 1024) {                                                                        \
+            static const hipError_t once = hipFuncSetAttribute((const void *)fwht_block_rows_kernel<T, LOG2W, NTV, PIPEV>, \
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+            (void)once;                                                                                          \
+        }                                                                                                        \
+        hipLaunchKernelGGL((fwht_block_rows_kernel<T, LOG2W, NTV, PIPEV>), dim3((unsigned)grid), dim3(64 * W), smem, st, \
+                           (u32x4 *)dst, (const u32x4 *)src, n_rows, trace);                                     \
+    } while (0)
+    if constexpr (HAS_PIPE) {
+        if (nt && pipe) { WHVI_BLOCK_ROWS(true, true); return; }
+        if (pipe) { WHVI_BLOCK_ROWS(false, true); return; }
+    }
+    if (nt) WHVI_BLOCK_ROWS(true, false);
+    else WHVI_BLOCK_ROWS(false, false);
+#undef WHVI_BLOCK_ROWS
+}
+
 template <typename T, bool TUNABLE>
 inline int fwht_dispatch(void *dst, const void *src, int64_t rows, int32_t log2d, int variant, void *stream)
 {
@@ -277,29 +326,60 @@ inline int fwht_dispatch(void *dst, const void *src, int64_t rows, int32_t log2d
     constexpr int VEC = Elem<T>::VEC;
     const int64_t n_chunks = elems / VEC;   // whole 16-byte chunks
     const int64_t tail_elems = elems - n_chunks * VEC;
+    // WHVI_LONG_ROWS=passes: the round-1 path (2^LOW-element pieces + high-bit passes) for every long row, an A/B switch
+    static const bool passes_only = [] { const char *e = getenv("WHVI_LONG_ROWS"); return e && !strcmp(e, "passes"); }();
+    const bool block_rows = log2d > max_single_pass_log2d<T>() && !(passes_only && sizeof(T) != 2);
+    // (Rows of exactly two tiles -- f32 / i32 D = 8192, f64 D = 4096 -- stay with one 128-VGPR tile per wave: as 2-wave
+    // blocks f32 gains 4 % (5.58 -> 5.80 TB/s), i32 loses 5 % (6.07 -> 5.74), f64 loses 1.5 %; profiles/r02/block_rows_w2.log.)
+    if (block_rows && log2d <= max_block_log2d<T>()) {
+        switch (log2d - multi_pass_low_log2d<T>()) {
+        case 2: launch_block_rows<T, 2>(dst, src, rows, st); break;
+        case 3: launch_block_rows<T, 3>(dst, src, rows, st); break;
+        default: launch_block_rows<T, 4>(dst, src, rows, st); break;
+        }
+        return after_launch("fwht (block rows)");
+    }
     if constexpr (sizeof(T) != 2) if (log2d > max_single_pass_log2d<T>()) {
-        // pass 1: index bits [0, LOW) on contiguous 2^LOW-element pieces (src -> dst)
+        // Rows beyond one block: pass 1 = index bits [0, low) on contiguous pieces (src -> dst: 2^(LOW + 4)-element pieces,
+        // a block each, unless the switch above asks for single tiles), passes 2.. = bits [low, log2d), up to HBMAX at a
+        // time, in place on dst.  The passes run over row groups of <= 128 MiB one after the other, with cached
+        // accesses, so every pass after the first finds its input in the 256 MiB Infinity Cache and HBM sees about one
+        // read and one write of the data (WHVI_PASS_CHUNK_MIB: group size, 0 = whole buffer per pass as in round 1).
         constexpr int LOW = multi_pass_low_log2d<T>();
-        launch_rows<T, LOW, pick_k<T, LOW>(), false>(dst, src, n_chunks, 0, st);
-        // passes 2..: bits [LOW, log2d), up to HBMAX at a time, in place on dst
+        const int low = block_rows ? max_block_log2d<T>() : LOW;
         constexpr int HBMAX = 4;                               // 2^4 chunks = 64 accumulator VGPRs per thread
         constexpr int LV = ilog2(VEC);
-        for (int b0 = LOW; b0 < log2d;) {
-            const int hb = (log2d - b0 < HBMAX) ? (log2d - b0) : HBMAX;
-            const int64_t n_groups = n_chunks >> hb;
-            const unsigned grid = (unsigned)((n_groups + 255) / 256);
-            u32x4 *d = (u32x4 *)dst;
+        static const int64_t group_bytes = [] {
+            const char *e = getenv("WHVI_PASS_CHUNK_MIB");
+            return (int64_t)(e ? atoll(e) : 128) << 20;
+        }();
+        const int64_t row_bytes = (int64_t)sizeof(T) << log2d;
+        int64_t group_rows = group_bytes > 0 ? group_bytes / row_bytes : rows;
+        if (group_rows < 1) group_rows = 1;
+        for (int64_t r0 = 0; r0 < rows; r0 += group_rows) {
+            const int64_t n = rows - r0 < group_rows ? rows - r0 : group_rows;
+            char *gd = (char *)dst + r0 * row_bytes;
+            const char *gs = (const char *)src + r0 * row_bytes;
+            const int64_t g_chunks = (n << log2d) / VEC;
+            if (block_rows) launch_block_rows<T, 4>(gd, gs, (n << log2d) >> low, st);
+            else launch_rows<T, LOW, pick_k<T, LOW>(), false>(gd, gs, g_chunks, 0, st);
+            for (int b0 = low; b0 < log2d;) {
+                const int hb = (log2d - b0 < HBMAX) ? (log2d - b0) : HBMAX;
+                const int64_t n_groups = g_chunks >> hb;
+                const unsigned grid = (unsigned)((n_groups + 255) / 256);
+                u32x4 *d = (u32x4 *)gd;
 #define WHVI_HIGH(HB) hipLaunchKernelGGL((fwht_high_kernel<T, HB>), dim3(grid), dim3(256), 0, st, d, d, n_groups, b0 - LV)
-            switch (hb) {
-            case 1: WHVI_HIGH(1); break;
-            case 2: WHVI_HIGH(2); break;
-            case 3: WHVI_HIGH(3); break;
-            default:
-                if constexpr (HBMAX >= 4) WHVI_HIGH(4);
-                break;
-            }
+                switch (hb) {
+                case 1: WHVI_HIGH(1); break;
+                case 2: WHVI_HIGH(2); break;
+                case 3: WHVI_HIGH(3); break;
+                default:
+                    if constexpr (HBMAX >= 4) WHVI_HIGH(4);
+                    break;
+                }
 #undef WHVI_HIGH
-            b0 += hb;
+                b0 += hb;
+            }
         }
         return after_launch("fwht (multi-pass)");
     }

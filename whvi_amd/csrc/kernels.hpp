@@ -330,6 +330,198 @@ fwht_high_kernel(u32x4 *dst, const u32x4 *src, int64_t n_groups, int log2_stride
     for (int m = 0; m < R; ++m) dst[base + m * stride] = E::pack(v[m]);
 }
 
+// ---- rows of 4 .. 16 wave tiles in ONE pass: a block per row, the bits above the tile through LDS -------------
+// A row of D = 2^(LOW + LOG2W) elements is 2^LOG2W contiguous 64-VGPR tiles (LOW = 12 for 32-bit and 16-bit storage,
+// 11 for f64); wave w of the block owns tile w, runs the in-register network on index bits [0, LOW) and then the
+// block runs bits [LOW, LOW + LOG2W), which are the wave index, on a transposed view: the tile is handed through LDS
+// in two halves (8 of its 16 sixteen-byte register units at a time, W x 8 KiB of LDS), thread (w, lane) collects
+// unit slice w of the same lane from all W waves, runs the log2(W) butterfly stages across them, puts the results
+// back where it found them and every wave reads its own half back.  Same adds in the same (ascending) order as the
+// one-wave network and the reference's radix-2 loop -> same bits; one read and one write of the row instead of the
+// two or three passes of the piece + high-bit kernels, and 16-bit storage keeps its single rounding up to D = 65536.
+// LDS traffic is 4 x the row (2 writes + 2 reads per element) against 2 x through HBM at a sixth of the bandwidth per
+// CU: a fifth of the row's HBM time.  Measurements: DESIGN.md 5.1b, profiles/r02/long_rows_*.log.
+template <typename T> constexpr int block_tile_k() { return 256 / (Elem<T>::VEC * (int)sizeof(typename Elem<T>::acc)); }
+
+// One half of the exchange: register units [8 HALF, 8 HALF + 8) of every wave's tile (unit q = bytes [16 q, 16 q + 16)
+// of the flattened r[K][VEC]).  Compile-time indices throughout: with plain unrolled loops the f16 instantiation kept
+// half the tile in scratch.  Two block barriers; on return only the calling wave reads its own LDS region again, so
+// the next half (or row) may overwrite it without another barrier.
+template <typename A, int VEC, int K, int LOG2W, int HALF>
+__device__ __forceinline__ void block_rows_exchange(A (&r)[K][VEC], char *smem, const int wave, const int lane)
+{
+    constexpr int W = 1 << LOG2W;
+    constexpr int HALF_UNITS = 8;
+    constexpr int PIECE_BYTES = HALF_UNITS * 16 / W;      // what one thread takes from each wave
+    constexpr int PB = PIECE_BYTES >= 16 ? 16 : PIECE_BYTES;   // LDS access width: 16 bytes, 8 for W = 16
+    constexpr int NP = PIECE_BYTES / PB;                  // accesses per source wave
+    constexpr int EPP = PB / (int)sizeof(A);              // elements per access
+    constexpr int PPW = HALF_UNITS * 16 / PB;             // pieces per wave and lane
+    static_assert(K * VEC * (int)sizeof(A) == 256 && LOG2W >= 1 && LOG2W <= 4 && EPP >= 1, "64-VGPR tiles, 2..16 waves");
+    typedef uint32_t piece_t __attribute__((ext_vector_type(PB / 4)));
+    piece_t *lds = reinterpret_cast<piece_t *>(smem);     // [W][PPW][64] pieces
+    auto to_words = [](const A (&x)[EPP]) {
+        piece_t v;
+        static_for<0, EPP>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            if constexpr (sizeof(A) == 8) {
+                const uint64_t u = __builtin_bit_cast(uint64_t, x[i]);
+                v[2 * i] = (uint32_t)u;
+                v[2 * i + 1] = (uint32_t)(u >> 32);
+            } else v[i] = __builtin_bit_cast(uint32_t, x[i]);
+        });
+        return v;
+    };
+    auto from_words = [](const piece_t &v, A (&x)[EPP]) {
+        static_for<0, EPP>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            if constexpr (sizeof(A) == 8) x[i] = __builtin_bit_cast(A, ((uint64_t)v[2 * i + 1] << 32) | v[2 * i]);
+            else {
+                const uint32_t w32 = v[i];
+                x[i] = __builtin_bit_cast(A, w32);
+            }
+        });
+    };
+    // own half out
+    static_for<0, PPW>([&](auto P) {
+        constexpr int p = decltype(P)::value;
+        constexpr int f0 = (HALF * HALF_UNITS * 16 + p * PB) / (int)sizeof(A);
+        A x[EPP];
+        static_for<0, EPP>([&](auto I) { constexpr int i = decltype(I)::value; x[i] = r[(f0 + i) / VEC][(f0 + i) % VEC]; });
+        lds[(wave * PPW + p) * 64 + lane] = to_words(x);
+    });
+    __syncthreads();
+    // slice `wave` of every wave's half, the same lane: butterflies across the wave index
+    A x[W][NP][EPP];
+    static_for<0, W>([&](auto V) {
+        constexpr int v = decltype(V)::value;
+        static_for<0, NP>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            from_words(lds[(v * PPW + wave * NP + j) * 64 + lane], x[v][j]);
+        });
+    });
+    static_for<0, LOG2W>([&](auto S) {
+        constexpr int h = 1 << decltype(S)::value;
+        static_for<0, W>([&](auto V) {
+            constexpr int v = decltype(V)::value;
+            if constexpr ((v & h) == 0)
+                static_for<0, NP * EPP>([&](auto EI) {
+                    constexpr int e = decltype(EI)::value;
+                    bfly(x[v][e / EPP][e % EPP], x[v | h][e / EPP][e % EPP]);
+                });
+        });
+    });
+    static_for<0, W>([&](auto V) {
+        constexpr int v = decltype(V)::value;
+        static_for<0, NP>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            lds[(v * PPW + wave * NP + j) * 64 + lane] = to_words(x[v][j]);
+        });
+    });
+    __syncthreads();
+    // own half back
+    static_for<0, PPW>([&](auto P) {
+        constexpr int p = decltype(P)::value;
+        constexpr int f0 = (HALF * HALF_UNITS * 16 + p * PB) / (int)sizeof(A);
+        A y[EPP];
+        from_words(lds[(wave * PPW + p) * 64 + lane], y);
+        static_for<0, EPP>([&](auto I) { constexpr int i = decltype(I)::value; r[(f0 + i) / VEC][(f0 + i) % VEC] = y[i]; });
+    });
+}
+
+// PIPE = false: one row per block and out (grid = rows).  PIPE = true (16-wave blocks: ONE block fits a CU, so nothing
+// else hides its load / butterfly / store phases -- profiles/r02/block_rows_trace.log: 29 us per row of which 8 us pass
+// between a block's last store and its successor's first load): a persistent block walks rows with a grid stride, stores
+// each half of the tile as soon as its exchange is done and asks for the same half of the NEXT row right behind those
+// stores, into the registers they vacate, so loads and stores are in flight while the other half is exchanged.
+template <typename T, int LOG2W, bool NT, bool PIPE>
+__global__ void __launch_bounds__(64 << LOG2W)
+    // exactly 4 waves per SIMD: 128 VGPRs, 16 waves per CU (two 512-thread blocks; LDS allows no more than that anyway)
+    __attribute__((amdgpu_waves_per_eu(4, 4)))
+fwht_block_rows_kernel(u32x4 *dst, const u32x4 *src, int64_t n_rows, uint64_t *trace)   // trace: -DWHVI_BLOCK_TRACE builds only
+{
+    using E = Elem<T>;
+    using A = typename E::acc;
+    constexpr int VEC = E::VEC;
+    constexpr int K = block_tile_k<T>();
+    constexpr int W = 1 << LOG2W;
+    constexpr int TILE = 64 * K;                          // storage chunks per wave tile
+    constexpr int LOW = ilog2(TILE * VEC);
+    extern __shared__ __attribute__((aligned(16))) char whvi_smem[];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int64_t row = blockIdx.x;
+    if (NT && !PIPE && (gridDim.x & 7) == 0) row = (row & 7) * (int64_t)(gridDim.x >> 3) + (row >> 3);   // XCD-contiguous
+    // trace (tools/probe_block_trace.py, -DWHVI_BLOCK_TRACE builds only): five 100 MHz timestamps + the hardware id per
+    // row, written by lane 0 of wave 0.  The scheduling fences stay in production builds: they keep the compiler from
+    // hoisting the next phase's loads over this one, which is what holds the kernel at 128 VGPRs without scratch.
+    auto stamp = [&](int slot) {
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef WHVI_BLOCK_TRACE
+        if (trace != nullptr && wave == 0 && lane == 0) trace[row * 8 + slot] = wall_clock64();
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+    };
+    if (row >= n_rows) return;
+    auto load_chunks = [&](int64_t rw, u32x4 (&raw)[K], auto HALF) {
+        const u32x4 *p = src + (rw * W + wave) * TILE + lane;
+        static_for<0, K / 2>([&](auto KK) {
+            constexpr int k = decltype(HALF)::value * (K / 2) + decltype(KK)::value;
+            raw[k] = ld16<NT>(p + k * 64);
+        });
+    };
+    auto store_chunks = [&](int64_t rw, A (&r)[K][VEC], auto HALF) {
+        u32x4 *tile = dst + (rw * W + wave) * TILE;
+        static_for<0, K / 2>([&](auto KK) {
+            constexpr int k = decltype(HALF)::value * (K / 2) + decltype(KK)::value;
+            if constexpr (NT) tile_store_stream(tile, lane, k, E::pack(r[k]), TILE * 16);
+            else tile[k * 64 + lane] = E::pack(r[k]);
+        });
+    };
+    stamp(0);
+#ifdef WHVI_BLOCK_TRACE
+    if (trace != nullptr && wave == 0 && lane == 0) {
+        uint32_t hw_id, xcc_id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+        trace[row * 8 + 5] = ((uint64_t)xcc_id << 32) | hw_id;   // (persistent grids: the block's first row only)
+    }
+#endif
+    u32x4 raw[K];
+    load_chunks(row, raw, IC<0>{});
+    load_chunks(row, raw, IC<1>{});
+    // one row; MORE at compile time (the last row is peeled): a run-time condition around the prefetch would keep the
+    // old chunks alive into the merge and double the live registers
+    auto one_row = [&](auto MORE) {
+        constexpr bool more = decltype(MORE)::value;
+        const int64_t next = row + gridDim.x;
+        A r[K][VEC];
+#pragma unroll
+        for (int k = 0; k < K; ++k) E::unpack(raw[k], r[k]);
+        stamp(1);
+        fwht_tile<A, VEC, K, LOW, POLICY_DPP, 0>(r, lane);
+        stamp(2);                                             // own tile loaded and transformed
+        block_rows_exchange<A, VEC, K, LOG2W, 0>(r, whvi_smem, wave, lane);
+        if constexpr (PIPE) store_chunks(row, r, IC<0>{});
+        if constexpr (more) load_chunks(next, raw, IC<0>{});
+        block_rows_exchange<A, VEC, K, LOG2W, 1>(r, whvi_smem, wave, lane);
+        stamp(3);                                             // exchange done
+        if constexpr (!PIPE) store_chunks(row, r, IC<0>{});
+        store_chunks(row, r, IC<1>{});
+        if constexpr (more) load_chunks(next, raw, IC<1>{});
+        stamp(4);                                             // stores issued
+    };
+    if constexpr (PIPE) {
+        while (row + gridDim.x < n_rows) {
+            one_row(std::true_type{});
+            row += gridDim.x;
+            stamp(0);
+        }
+    }
+    one_row(std::false_type{});
+}
+
 // Rows shorter than one 16-byte chunk whose total size is not a multiple of 16 bytes leave a
 // sub-chunk tail of whole rows; one thread per tail row finishes it.
 template <typename T, int LOG2D>
