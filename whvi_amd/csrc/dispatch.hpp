@@ -298,11 +298,9 @@ inline void launch_block_rows(void *dst, const void *src, int64_t n_rows, hipStr
     note_launch<T>("fwht_block_rows_kernel", LOG2W, nt, pipe);
 #define WHVI_BLOCK_ROWS(NTV, PIPEV)                                                                              \
     do {                                                                                                         \
-        if constexpr (smem > 64 * 1024) {                                                                        \
-            static const hipError_t once = hipFuncSetAttribute((const void *)fwht_block_rows_kernel<T, LOG2W, NTV, PIPEV>, \
-                                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
-            (void)once;                                                                                          \
-        }                                                                                                        \
+        if constexpr (smem > 64 * 1024)   /* per launch, not once: the attribute belongs to the CURRENT device's copy */ \
+            (void)hipFuncSetAttribute((const void *)fwht_block_rows_kernel<T, LOG2W, NTV, PIPEV>,                \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                    \
         hipLaunchKernelGGL((fwht_block_rows_kernel<T, LOG2W, NTV, PIPEV>), dim3((unsigned)grid), dim3(64 * W), smem, st, \
                            (u32x4 *)dst, (const u32x4 *)src, n_rows, trace);                                     \
     } while (0)
