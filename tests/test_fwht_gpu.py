@@ -262,6 +262,24 @@ def test_block_rows_at_streaming_size(dtype, log2d, hip_lib):
         del y, x
 
 
+@pytest.mark.parametrize("dtype,log2d", [(torch.float32, 16), (torch.float32, 14), (torch.float64, 13), (torch.int32, 16)])
+def test_block_rows_pipelined_cached_form(dtype, log2d, hip_lib):
+    """Exactly 256 MiB in place is the one size at which the persistent pipelined grid runs with CACHED accesses (enough
+    rows per resident block, not yet a stream): its own instantiation, checked like the streaming one."""
+    d = 1 << log2d
+    rows = (256 << 20) // (d * torch.empty(0, dtype=dtype).element_size())
+    g = torch.Generator(device=DEV).manual_seed(11 + log2d)
+    x = torch.randint(-3, 4, (rows, d), device=DEV, generator=g, dtype=torch.int32).to(dtype)
+    keep = [0, 1, 255, 256, 257, rows // 2 + 1, rows - 2, rows - 1]     # first, second and last trip of several blocks
+    want = _oracle(x[keep].cpu())
+    y = x.clone()
+    _hip.fwht_rows(y, out=y)
+    assert _hip.last_kernel().endswith("false, true>"), _hip.last_kernel()
+    assert torch.equal(y[keep].cpu().view(torch.uint8), want.view(torch.uint8)), (dtype, log2d)
+    _hip.fwht_rows(y, out=y)
+    assert torch.equal(y, x * d), (dtype, log2d)
+
+
 def test_half_types_reject_multi_pass_lengths(hip_lib):
     """fp16 / bf16 promise one rounding of the f32 result; a second pass would round the intermediate, so rows
     beyond the one-block limit (D = 65536) are refused instead of silently losing bits."""

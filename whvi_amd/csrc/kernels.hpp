@@ -92,14 +92,57 @@ template <> struct Elem<__half> {
     static constexpr int VEC = 8;
     static __device__ __forceinline__ void unpack(const u32x4 &raw, acc (&o)[VEC])
     {
+        // The high half goes through an explicit shift.  Written as plain C++ the compiler folds shift + convert into
+        // v_cvt_f32_f16_sdwa (src0_sel:WORD_1), and the stream runs 2.6 % slower: 6.21 vs 6.37 TB/s at D = 4096, 2^20 rows,
+        // interleaved A/B on identical finite data (tools/probe_f16_convert.py, profiles/r02/f16_convert_ab.log; with
+        // bf16's bit moves in place of the converts -- wrong values, timing only -- 6.41).  Same values either way.
+#ifndef WHVI_F16_UNPACK
+#define WHVI_F16_UNPACK 1
+#endif
+#if WHVI_F16_UNPACK == 2   /* timing experiment only: bf16's bit moves (wrong values) */
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t u = raw[i];
+            o[2 * i] = __uint_as_float(u << 16);
+            o[2 * i + 1] = __uint_as_float(u & 0xFFFF0000u);
+        }
+#elif WHVI_F16_UNPACK == 1 || WHVI_F16_UNPACK == 3
+#if WHVI_F16_UNPACK == 3
+#define WHVI_F16_ASM asm volatile
+#else
+#define WHVI_F16_ASM asm
+#endif
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float lo, hi;
+            uint32_t sh;
+            WHVI_F16_ASM("v_cvt_f32_f16 %0, %1" : "=v"(lo) : "v"(raw[i]));
+            WHVI_F16_ASM("v_lshrrev_b32 %0, 16, %1" : "=v"(sh) : "v"(raw[i]));
+            WHVI_F16_ASM("v_cvt_f32_f16 %0, %1" : "=v"(hi) : "v"(sh));
+            o[2 * i] = lo;
+            o[2 * i + 1] = hi;
+        }
+#undef WHVI_F16_ASM
+#else   /* 0: the compiler's form (SDWA operand for the high half) */
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             o[2 * i] = __half2float(__ushort_as_half((unsigned short)(raw[i] & 0xFFFFu)));
             o[2 * i + 1] = __half2float(__ushort_as_half((unsigned short)(raw[i] >> 16)));
         }
+#endif
     }
     static __device__ __forceinline__ u32x4 pack(const acc (&v)[VEC])
     {
+#if defined(WHVI_F16_PACK_EXP) && WHVI_F16_PACK_EXP == 1   /* timing experiment only: bf16's pack (wrong values) */
+        u32x4 rr;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint32_t w;
+            asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(v[2 * i]), "v"(v[2 * i + 1]));
+            rr[i] = w;
+        }
+        return rr;
+#endif
         // <2 x float> -> <2 x half> fptrunc (round to nearest even) selects gfx950's v_cvt_pk_f16_f32:
         // one instruction per output dword instead of two converts and an or
         typedef float f32x2_t __attribute__((ext_vector_type(2)));
@@ -136,8 +179,22 @@ template <> struct Elem<__hip_bfloat16> {
     static __device__ __forceinline__ u32x4 pack(const acc (&v)[VEC])
     {
         u32x4 r;
+#ifndef WHVI_BF16_PACK
+#define WHVI_BF16_PACK 1
+#endif
+#if WHVI_BF16_PACK == 1
+        // one v_cvt_pk_bf16_f32 per output dword (low half <- first operand).  From `rne(lo) | rne(hi) << 16` the compiler
+        // makes TWO of them (upper lane unused) plus a v_or_b32_sdwa: 192 instead of 64 instructions per tile.
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint32_t w;
+            asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(v[2 * i]), "v"(v[2 * i + 1]));
+            r[i] = w;
+        }
+#else
 #pragma unroll
         for (int i = 0; i < 4; ++i) r[i] = rne(v[2 * i]) | (rne(v[2 * i + 1]) << 16);
+#endif
         return r;
     }
 };
