@@ -280,6 +280,33 @@ def test_block_rows_pipelined_cached_form(dtype, log2d, hip_lib):
     assert torch.equal(y, x * d), (dtype, log2d)
 
 
+def test_long_row_launch_forms_agree(hip_lib):
+    """The A/B switches of the long-row path are read once per process, so each form runs in a child: round 1's pieces +
+    high-bit passes (WHVI_LONG_ROWS=passes), one row per block and the pipelined grid (WHVI_BLOCK_PIPE=0 / 1) and the
+    multi-pass form without row groups (WHVI_PASS_CHUNK_MIB=0) must all return the production launch's bits."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, hashlib, torch; sys.path.insert(0, %r); from whvi_amd import _hip\n"
+            "h = hashlib.sha256()\n"
+            "for dt, l, rows in ((torch.float32, 14, 4100), (torch.float32, 16, 1030), (torch.float64, 13, 4100), (torch.int32, 15, 70),"
+            " (torch.float32, 18, 5), (torch.float64, 17, 3)):\n"
+            "    g = torch.Generator(device='cuda').manual_seed(l)\n"
+            "    x = torch.randint(-99, 100, (rows, 1 << l), device='cuda', generator=g, dtype=torch.int32).to(dt)\n"
+            "    if dt != torch.int32: x = x * 0.37\n"
+            "    h.update(_hip.fwht_rows(x).cpu().numpy().tobytes())\n"
+            "print('digest', h.hexdigest())\n") % root
+    digests = {}
+    for name, env in (("production", {}), ("passes", {"WHVI_LONG_ROWS": "passes"}), ("pipe0", {"WHVI_BLOCK_PIPE": "0"}),
+                      ("pipe1", {"WHVI_BLOCK_PIPE": "1"}), ("ungrouped", {"WHVI_PASS_CHUNK_MIB": "0"})):
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=root,
+                             env={**os.environ, **env})
+        assert out.returncode == 0, (name, out.stderr[-2000:])
+        digests[name] = [ln for ln in out.stdout.splitlines() if ln.startswith("digest")][0]
+    assert len(set(digests.values())) == 1, digests
+
+
 def test_half_types_reject_multi_pass_lengths(hip_lib):
     """fp16 / bf16 promise one rounding of the f32 result; a second pass would round the intermediate, so rows
     beyond the one-block limit (D = 65536) are refused instead of silently losing bits."""
