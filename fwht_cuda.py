@@ -4,8 +4,10 @@ The reference imports this name unconditionally (``import fwht_cuda`` at
 src/fwht/cuda/fwht.py:2, hence src/weights.py:8, test/walsh.py:6, benchmarks/walsh_plot.py:11)
 and calls exactly one function, ``fwht_cuda.fwht(X)`` (src/fwht/cuda/fwht_cuda.cpp:5-18).  This
 module provides that function on top of the MI355X HIP library (``whvi_amd/libwhvi_hip.so``,
-C ABI in ``include/whvi_hip.h``), so the reference's own ``src`` package, tests and benchmarks
-run unchanged with this repo root on ``sys.path``.
+C ABI in ``include/whvi_hip.h``).  With the repo root on ``sys.path`` the reference's tests and
+benchmarks run unchanged on the alias package ``src/``; to keep the reference's
+OWN ``src`` package and swap only this module and ``fwht_cpp``, put ``dropin/`` on the path instead
+(INTEGRATION.md 1).
 
 Importing the module never touches the GPU or the native library (the reference's CPU path
 imports it too); the library is loaded on the first call and a missing library is an error.

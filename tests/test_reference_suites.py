@@ -1,0 +1,59 @@
+"""The reference's OWN unit tests (test/walsh.py, test/utils.py, test/networks.py, test/likelihoods.py -- SURVEY.md 2,
+row 16: "consumers that must pass unchanged") run against this repo, in the two ways INTEGRATION.md 1 / 1b describes.
+Only where the reference checkout exists (the build container); nothing of it is copied or written: the suites run in a
+child process with the checkout as working directory and bytecode writing off.  Without a GPU the two `test_cuda_*`
+cases cannot run (they are restated in tests/test_fwht_gpu.py::test_cuda_simple_and_large_like_reference); everything
+else must pass."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+REFERENCE = "/root/reference"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SUITES = ["test.walsh", "test.utils", "test.networks", "test.likelihoods"]
+
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REFERENCE, "test")), reason="no reference checkout here")
+
+
+def _run(pythonpath, code=None):
+    env = {**os.environ, "PYTHONPATH": pythonpath, "PYTHONDONTWRITEBYTECODE": "1"}
+    cmd = [sys.executable, "-c", code] if code else [sys.executable, "-m", "unittest", "-v", *SUITES]
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=REFERENCE, env=env)
+
+
+def _check_suites(out):
+    text = out.stderr + out.stdout
+    ran = re.search(r"Ran (\d+) tests", text)
+    assert ran and int(ran.group(1)) == 13, text[-3000:]
+    bad = re.findall(r"^(?:ERROR|FAIL): (\w+)", text, flags=re.M)
+    if torch.cuda.is_available():
+        assert bad == [] and out.returncode == 0, text[-3000:]
+    else:
+        assert sorted(bad) == ["test_cuda_large", "test_cuda_simple"], text[-3000:]     # need a GPU, nothing else may fail
+        assert text.count("No HIP GPUs are available") >= 2 or text.count("Torch not compiled with CUDA") >= 2, text[-3000:]
+
+
+def test_reference_suites_with_only_the_native_modules_swapped():
+    """`dropin/` on the path -- the reference's own `src` package (weights, layers, networks,
+    likelihoods, utils, the three FWHT front-ends) on top of this repo's `fwht_cuda` / `fwht_cpp`."""
+    path = os.path.join(ROOT, "dropin")
+    where = _run(path, "import fwht_cuda, fwht_cpp, src.weights, src.fwht.cpp.fwht as f; "
+                       "print(src.weights.__file__); print(fwht_cuda.__file__); print(fwht_cpp.__file__); print(f.__file__)")
+    assert where.returncode == 0, where.stderr[-2000:]
+    weights, cuda_mod, cpp_mod, front = where.stdout.split()
+    assert weights.startswith(REFERENCE) and front.startswith(REFERENCE), "the reference's own src package must be the one in use"
+    assert cuda_mod.startswith(path) and cpp_mod.startswith(path)
+    _check_suites(_run(path))
+
+
+def test_reference_suites_on_the_alias_package():
+    """the repo root on the path -- `src.*` resolves to the alias package, i.e. to `whvi_amd`."""
+    where = _run(ROOT, "import src.weights, src.layers; print(src.weights.__file__); print(src.layers.WHVILinear.__module__)")
+    assert where.returncode == 0, where.stderr[-2000:]
+    weights, module = where.stdout.split()
+    assert weights.startswith(ROOT) and module.startswith("whvi_amd")
+    _check_suites(_run(ROOT))
