@@ -57,3 +57,13 @@ def test_reference_suites_on_the_alias_package():
     weights, module = where.stdout.split()
     assert weights.startswith(ROOT) and module.startswith("whvi_amd")
     _check_suites(_run(ROOT))
+
+
+def test_reference_benchmark_script_runs_on_the_dropin_modules():
+    """benchmarks/walsh.py is a consumer too -- dense H product against `FWHTFunction` of
+    src/fwht/cpp on (1, D, D) inputs up to D = 8192 (benchmarks/walsh.py:16-42).  Must run to the end unchanged."""
+    env = {**os.environ, "PYTHONPATH": os.path.join(ROOT, "dropin"), "PYTHONDONTWRITEBYTECODE": "1"}
+    out = subprocess.run([sys.executable, "-m", "benchmarks.walsh"], capture_output=True, text=True, timeout=900,
+                         cwd=REFERENCE, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.count("Evaluating benchmark_FWHT_speed_") == 4 and out.stdout.count("FWHTFunction_:") == 4, out.stdout
