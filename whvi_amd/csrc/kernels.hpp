@@ -504,6 +504,11 @@ fwht_block_rows_kernel(u32x4 *dst, const u32x4 *src, int64_t n_rows, uint64_t *t
     constexpr int W = 1 << LOG2W;
     constexpr int TILE = 64 * K;                          // storage chunks per wave tile
     constexpr int LOW = ilog2(TILE * VEC);
+    // first half of the tile stored as soon as its exchange is done (its write-back drains under the second exchange):
+    // always when pipelined; otherwise where the block is bound by its own phases rather than by HBM -- 16 waves (f64
+    // 4.85 -> 5.01 TB/s, fp16 4.01 -> 4.2) and 16-bit storage (8 waves 5.66 -> 5.8) -- but not for 8-wave blocks of 4- / 8-byte
+    // storage, which lose 1.5 % to it (profiles/r02/block_rows_early_store_ab.log)
+    constexpr bool EARLY = PIPE || LOG2W == 4 || sizeof(T) == 2;
     extern __shared__ __attribute__((aligned(16))) char whvi_smem[];
 
     const int lane = threadIdx.x & 63;
@@ -560,11 +565,11 @@ fwht_block_rows_kernel(u32x4 *dst, const u32x4 *src, int64_t n_rows, uint64_t *t
         fwht_tile<A, VEC, K, LOW, POLICY_DPP, 0>(r, lane);
         stamp(2);                                             // own tile loaded and transformed
         block_rows_exchange<A, VEC, K, LOG2W, 0>(r, whvi_smem, wave, lane);
-        if constexpr (PIPE) store_chunks(row, r, IC<0>{});
+        if constexpr (EARLY) store_chunks(row, r, IC<0>{});
         if constexpr (more) load_chunks(next, raw, IC<0>{});
         block_rows_exchange<A, VEC, K, LOG2W, 1>(r, whvi_smem, wave, lane);
         stamp(3);                                             // exchange done
-        if constexpr (!PIPE) store_chunks(row, r, IC<0>{});
+        if constexpr (!EARLY) store_chunks(row, r, IC<0>{});
         store_chunks(row, r, IC<1>{});
         if constexpr (more) load_chunks(next, raw, IC<1>{});
         stamp(4);                                             // stores issued
