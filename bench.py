@@ -141,10 +141,19 @@ def timed(step, steps, warmup, device, world):
     return wall, ev_ms
 
 
-def event_ms(fn, iters=10, warm=2):
+def event_ms(fn, iters=10, warm=2, warm_ms=0.0):
+    """Average ms of ``fn`` over ``iters`` launches after ``warm`` untimed ones -- and, for kernels of a fraction of a
+    millisecond, after at least ``warm_ms`` of them: the clocks take ~30 ms of continuous work to ramp, which 20 launches
+    of a 0.2 ms kernel do not provide (the first shape measured in a section would read 10 % low)."""
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
+    if warm_ms > 0:
+        t0 = time.perf_counter()
+        while (time.perf_counter() - t0) * 1e3 < warm_ms:
+            for _ in range(10):
+                fn()
+            torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
@@ -311,7 +320,7 @@ def _extra_long_rows(device):
         rows = (1 << 32) // (esize * d)
         x = (torch.randn(rows, d, device=device) * 0.25).to(dtype)
         ms = event_ms_each(lambda: _hip.fwht_rows(x, out=x),
-                           lambda i: x.mul_(2.0 ** (-(log2d // 2) - (i & 1) * (log2d & 1))), iters=8, warm=4)
+                           lambda i: x.mul_(2.0 ** (-(log2d // 2) - (i & 1) * (log2d & 1))), iters=8, warm=12)
         key = f"{str(dtype)[6:]}_D={d}"
         out[key] = _rate(rows, d, esize, ms)
         out[key].update(kernel=_hip.last_kernel(), values_finite=_finite(x))
@@ -392,7 +401,7 @@ def _extra_wbar_fwd(device):
 
         def run():
             res[0] = _hip.wbar_fwd(s1, u, s2, D, base=base, first=1)
-        ms = event_ms(run, iters=20, warm=20)
+        ms = event_ms(run, iters=20, warm=20, warm_ms=50)
         gbs = J * S * D * D * 4 / (ms * 1e-3) / 1e9
         out[key] = {"matrices": J * S, "D": D, "ms": round(ms, 4), "GB_per_s_written": round(gbs, 1),
                     "frac_of_peak": round(gbs / HBM_PEAK_GBS, 4), "kernel": _hip.last_kernel(),
@@ -417,7 +426,7 @@ def _extra_wbar_bwd(device):
 
         def run():
             res[0] = _hip.wbar_bwd(gw, s1, u, s2, mean=mean)
-        ms = event_ms(run, iters=20, warm=20)
+        ms = event_ms(run, iters=20, warm=20, warm_ms=50)
         gbs = gw.numel() * 4 / (ms * 1e-3) / 1e9
         out[key] = {"matrices": J * S, "D": D, "ms": round(ms, 4), "GB_per_s": round(gbs, 1),
                     "frac_of_peak": round(gbs / HBM_PEAK_GBS, 4), "kernel": _hip.last_kernel(),
