@@ -35,3 +35,27 @@ def test_roofline_traffic_is_tied_to_the_build(monkeypatch):
     monkeypatch.setattr(bench, "kernel_source_hash", lambda: "0" * 64)
     value, note = bench.recorded_traffic("fwht_f32_D4096_rows1048576", rec["kernel_symbol"])
     assert value is None and "re-collect" in note
+
+
+def test_setup_py_builds_an_installable_tree(tmp_path):
+    """setup.py (the counterpart of the reference's src/fwht/{cuda,cpp}/setup.py): `build` runs make and lays out the
+    package with both native libraries inside it and the two top-level modules the reference imports; the result works
+    from a clean directory with nothing of the checkout on the path."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "setup.py", "-q", "build", "--build-base", str(tmp_path / "b")],
+                         capture_output=True, text=True, timeout=1800, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lib = tmp_path / "b" / "lib"
+    for rel in ("fwht_cuda.py", "fwht_cpp.py", "whvi_amd/libwhvi_hip.so", "whvi_amd/libwhvi_cpu.so", "whvi_amd/fwht/cuda.py"):
+        assert (lib / rel).exists(), rel
+    assert not (lib / "src").exists(), "the alias package must not be installed"
+    code = ("import torch, fwht_cpp, fwht_cuda, whvi_amd, ctypes; from whvi_amd import _hip\n"
+            "assert whvi_amd.__file__.startswith(%r), whvi_amd.__file__\n"
+            "assert fwht_cpp.forward(torch.tensor([[1., 2, 3, 4]])).tolist() == [[10., -2., -4., 0.]]\n"
+            "assert _hip.LIB_PATH.startswith(%r) and ctypes.CDLL(_hip.LIB_PATH).whvi_hip_abi_version() >= 1\n") % (str(lib), str(lib))
+    run = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=str(tmp_path),
+                         env={**os.environ, "PYTHONPATH": str(lib)})
+    assert run.returncode == 0, run.stderr[-2000:]
