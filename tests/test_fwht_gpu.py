@@ -280,6 +280,43 @@ def test_block_rows_pipelined_cached_form(dtype, log2d, hip_lib):
     assert torch.equal(y, x * d), (dtype, log2d)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_16bit_special_values(dtype, hip_lib):
+    """Subnormals, signed zeros, the largest finite values (sums overflow to inf when the row is stored), inf and NaN in
+    16-bit storage: converts in, f32 butterflies, ONE rounding out -- the same bits as the oracle's f32 transform
+    rounded once by torch (NaN compared by position).  Covers the DPP network (small problems), the LDS-staged network
+    (streams) and the block-per-row kernel; the fp16 unpack is hand-written (explicit shift form), so its subnormal
+    handling is pinned here."""
+    info = torch.finfo(dtype)
+    specials = torch.tensor([0.0, -0.0, info.tiny, -info.tiny, info.tiny / 4, -info.tiny / 8, info.smallest_normal * 1.5,
+                             info.max, -info.max, info.max / 2, 1.0, -1.0, float("inf"), -float("inf"), float("nan"), 3.0],
+                            dtype=torch.float32).to(dtype)
+    g = torch.Generator().manual_seed(3)
+
+    def check(x, keep=None):
+        rows = slice(None) if keep is None else keep
+        want = _oracle(x[rows].cpu())
+        got = _hip.fwht_rows(x.to(DEV))[rows].cpu()
+        nan_w, nan_g = torch.isnan(want.float()), torch.isnan(got.float())
+        assert torch.equal(nan_w, nan_g)
+        assert torch.equal(got.view(torch.int16)[~nan_g], want.view(torch.int16)[~nan_w])
+
+    for d in (8, 64, 4096, 1 << 14):
+        x = (torch.randn(33, d, generator=g) * 0.5).to(dtype)
+        x[1, :16 if d >= 16 else d] = specials[:16 if d >= 16 else d]         # everything at once: NaN / inf rows
+        x[2] = specials[torch.randint(0, 12, (d,), generator=g)]                # finite specials only: overflow + subnormal sums
+        x[3] = specials[torch.randint(2, 7, (d,), generator=g)]                 # subnormal-sized values only
+        x[4, ::7] = specials[7]
+        check(x)
+    d, rows = 4096, (320 << 20) // (4096 * 2) + 5                                # the streaming (LDS-staged) launch
+    x = (torch.randn(64, d, generator=g) * 0.5).to(dtype).repeat(rows // 64 + 1, 1)[:rows].contiguous()
+    x[5] = specials[torch.randint(0, 12, (d,), generator=g)]
+    x[rows - 2] = specials[torch.randint(2, 7, (d,), generator=g)]
+    x[rows // 2, :16] = specials
+    check(x, keep=[0, 5, rows // 2, rows - 2, rows - 1])
+    assert "2, false, true, 256, 1" in _hip.last_kernel(), _hip.last_kernel()   # POLICY_LDS, streaming
+
+
 def test_long_row_launch_forms_agree(hip_lib):
     """The A/B switches of the long-row path are read once per process, so each form runs in a child: round 1's pieces +
     high-bit passes (WHVI_LONG_ROWS=passes), one row per block and the pipelined grid (WHVI_BLOCK_PIPE=0 / 1) and the
