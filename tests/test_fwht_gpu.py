@@ -317,6 +317,48 @@ def test_16bit_special_values(dtype, hip_lib):
     assert "2, false, true, 256, 1" in _hip.last_kernel(), _hip.last_kernel()   # POLICY_LDS, streaming
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_float_special_values(dtype, hip_lib):
+    """f32 / f64 rows holding subnormals, signed zeros, huge values (sums overflow), inf and NaN, through the cached
+    (unsigned network) and the streaming launches (f32 D = 2048: the SIGNED network) and the block-per-row kernel:
+    NaN in the same places as the oracle, every other value equal, and bit-identical wherever the oracle's value is not
+    a zero (the signed network's documented exception: a NEGATIVE zero result comes out as +0)."""
+    info = torch.finfo(dtype)
+    specials = torch.tensor([0.0, -0.0, info.tiny, -info.tiny, info.tiny / 4, -info.tiny / 8, info.smallest_normal * 1.5,
+                             info.max, -info.max, info.max / 2, 1.0, -1.0, float("inf"), -float("inf"), float("nan"), 3.0],
+                            dtype=dtype)
+    g = torch.Generator().manual_seed(5)
+    ibits = torch.int32 if dtype == torch.float32 else torch.int64
+
+    def check(x, keep=None):
+        rows = slice(None) if keep is None else keep
+        want = _oracle(x[rows].cpu())
+        got = _hip.fwht_rows(x.to(DEV))[rows].cpu()
+        nan_w, nan_g = torch.isnan(want), torch.isnan(got)
+        assert torch.equal(nan_w, nan_g)
+        ok = ~nan_w
+        assert torch.equal(got[ok], want[ok])                                   # values (-0 == +0 here)
+        nz = ok & (want != 0)
+        assert torch.equal(got.view(ibits)[nz], want.view(ibits)[nz])           # bits wherever the value is not a zero
+
+    for d in (8, 64, 2048, 4096, 1 << 14):
+        x = torch.randn(33, d, generator=g, dtype=dtype)
+        x[1, :16 if d >= 16 else d] = specials[:16 if d >= 16 else d]
+        x[2] = specials[torch.randint(0, 12, (d,), generator=g)]
+        x[3] = specials[torch.randint(0, 7, (d,), generator=g)]                 # zeros of both signs and subnormal-sized values
+        x[4] = -0.0                                                             # a row of negative zeros: the result is -0 everywhere
+        check(x)
+    d = 2048
+    rows = (320 << 20) // (d * specials.element_size()) + 3                     # the streaming launch
+    x = torch.randn(64, d, generator=g, dtype=dtype).repeat(rows // 64 + 1, 1)[:rows].contiguous()
+    x[5] = specials[torch.randint(0, 12, (d,), generator=g)]
+    x[6] = -0.0
+    x[rows - 2] = specials[torch.randint(0, 7, (d,), generator=g)]
+    x[rows // 2, :16] = specials
+    check(x, keep=[0, 5, 6, rows // 2, rows - 2, rows - 1])
+    assert "true, 256, 1" in _hip.last_kernel() or "1024" in _hip.last_kernel(), _hip.last_kernel()
+
+
 def test_long_row_launch_forms_agree(hip_lib):
     """The A/B switches of the long-row path are read once per process, so each form runs in a child: round 1's pieces +
     high-bit passes (WHVI_LONG_ROWS=passes), one row per block and the pipelined grid (WHVI_BLOCK_PIPE=0 / 1) and the
