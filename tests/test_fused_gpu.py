@@ -50,6 +50,37 @@ def test_col_axis_bit_exact(log2d, dtype, hip_lib):
     assert np.array_equal(_bits(got), _bits(want))
 
 
+@pytest.mark.parametrize("log2d,dtype", [(4, np.float32), (9, np.float32), (11, np.float32), (12, np.float32), (11, np.float64)])
+def test_col_axis_special_values(log2d, dtype, hip_lib):
+    """Zeros of both signs, subnormals, huge values, inf and NaN in the data AND in the scale vectors, through the fused
+    pipeline (its lane stages run as signed fused multiply-adds): NaN in the same places as the oracle, every other
+    value equal, and bit-identical wherever the oracle's value is not a zero."""
+    d, S, B = 1 << log2d, 3, 11
+    rng = np.random.default_rng(40 + log2d)
+    info = np.finfo(dtype)
+    specials = np.array([0.0, -0.0, info.tiny, -info.tiny, info.tiny / 4, -info.tiny / 8, info.max, -info.max, info.max / 2,
+                         1.0, -1.0, 3.0, np.inf, -np.inf, np.nan], dtype=dtype)
+    x = rng.standard_normal((B * S, d)).astype(dtype)
+    x[1, :15] = specials
+    x[2] = specials[rng.integers(0, 12, d)]                       # finite specials: overflow, cancellation, subnormal sums
+    x[3] = specials[rng.integers(0, 6, d)]
+    x[4] = -0.0
+    x[5] = 0.0
+    a, c = rng.standard_normal(d).astype(dtype), rng.standard_normal(d).astype(dtype)
+    b = rng.standard_normal((S, d)).astype(dtype)
+    a[::5], c[::7], b[1, ::3] = 0.0, -0.0, 0.0                    # zero scales of both signs
+    a[1], c[2], b[2, 3] = -1.0, info.tiny, info.max / 4
+    with np.errstate(all="ignore"):
+        want = oracle.pipeline(x, a, b, c, n_samples=S, sample_stride=1, axis="col")
+    got = _hip.fused_shs(_t(x), _t(a), _t(b), _t(c), axis="col", n_samples=S, sample_stride=1).cpu().numpy()
+    nan_w, nan_g = np.isnan(want), np.isnan(got)
+    assert np.array_equal(nan_w, nan_g)
+    ok = ~nan_w
+    assert np.array_equal(got[ok], want[ok])
+    nz = ok & (want != 0)
+    assert np.array_equal(_bits(got)[nz], _bits(want)[nz])
+
+
 @pytest.mark.parametrize("log2d", [2, 4, 7, 9, 10, 12])
 def test_row_axis_and_identity_input_bit_exact(log2d, hip_lib):
     d, S = 1 << log2d, 3
