@@ -21,7 +21,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch.autograd.function import once_differentiable
 
-from whvi_amd.utils import is_pow_of_2, kl_diag_normal
+from whvi_amd.utils import is_pow_of_2
 
 __all__ = ["FastfoodFunction", "WHVIFastfoodMatrix"]
 
@@ -111,9 +111,8 @@ class WHVIFastfoodMatrix(nn.Module):
 
     @property
     def kl(self):
-        dev = self.g_mu.device
-        return kl_diag_normal(self.g_mu, self.g_sigma, torch.zeros(self.D, device=dev),
-                              torch.ones(self.D, device=dev) * self.lambda_)
+        from whvi_amd.weights import _posterior_kl
+        return _posterior_kl(self.g_mu.unsqueeze(0), self.g_rho.unsqueeze(0), self.lambda_)
 
     def dense_weight(self, g):
         """The (D, D) matrix this layer applies for one g -- ``diag(s1) H diag(g) H diag(s2)`` -- built densely (tests,

@@ -187,6 +187,19 @@ def _reparam(g_mu, g_rho, eps, lambda_):
     return torch.cat((g_mu.unsqueeze(1), sigma.unsqueeze(1) * eps), dim=1), None
 
 
+def _posterior_kl(g_mu, g_rho, lambda_):
+    """``sum_j kl_diag_normal(g_mu[j], softplus(g_rho[j]), 0, lambda)`` for ``(J, D)`` parameters -- the ``kl``
+    property of every weight flavour (src/weights.py:52-64, :169).  float32 on the GPU: ONE launch of the
+    reparameterisation + KL kernel with zero samples (differentiable through its closed-form backward) instead of the
+    formula's ten tiny launches; otherwise the reference's formula (src/utils.py:49-71) as torch ops."""
+    if g_mu.device.type == "cuda" and g_mu.dtype == torch.float32:
+        eps = g_mu.new_empty((g_mu.shape[0], 0, g_mu.shape[1]))
+        kl = ReparamKLFunction.apply(g_mu, g_rho, eps, lambda_)[1]
+        return kl[0] if kl.numel() == 1 else kl.sum()
+    mu, sd = g_mu.reshape(-1), F.softplus(g_rho).reshape(-1)
+    return kl_diag_normal(mu, sd, torch.zeros_like(mu), torch.ones_like(mu) * lambda_)
+
+
 def _fresh_philox_seed():
     """Seed of a layer's in-kernel generator: drawn from torch's default CPU generator (so ``torch.manual_seed`` makes
     runs repeatable) and, inside a ``torch.distributed`` job, mixed with the RANK -- ranks usually share one
@@ -261,9 +274,7 @@ class WHVISquarePow2Matrix(nn.Module):
     def kl(self):
         """KL from the N(0, lambda I) prior to the posterior, via the reference's formula and
         argument convention (src/weights.py:52-64)."""
-        dev = self.g_mu.device
-        return kl_diag_normal(self.g_mu, self.g_sigma, torch.zeros(self.D, device=dev),
-                              torch.ones(self.D, device=dev) * self.lambda_)
+        return _posterior_kl(self.g_mu.unsqueeze(0), self.g_rho.unsqueeze(0), self.lambda_)
 
     def _w_bar_stack(self, u, rows=None, mean_plus=False):
         """``w_bar`` for every row of ``u`` (S, D) -> (S, D, D) (first ``rows`` rows on the GPU)."""
@@ -471,9 +482,7 @@ class WHVIStackedMatrix(nn.Module):
         if self._on_gpu():
             # one evaluation over all sub-matrices (they share lambda): the same sum of terms as the reference's
             # per-matrix loop, in one pass instead of stack x ~12 tiny launches
-            g_mu = self._stacked("g_mu").reshape(-1)
-            g_sigma = F.softplus(self._stacked("g_rho")).reshape(-1)
-            return kl_diag_normal(g_mu, g_sigma, torch.zeros_like(g_mu), torch.ones_like(g_mu) * self.lambda_)
+            return _posterior_kl(self._stacked("g_mu"), self._stacked("g_rho"), self.lambda_)
         return sum(weight.kl for weight in self.weight_matrices)
 
     def _stacked_w_bar(self, parts, mean_plus=False):
