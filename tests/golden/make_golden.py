@@ -19,6 +19,8 @@ import zlib
 import os
 import sys
 
+sys.dont_write_bytecode = True      # importing the reference must not leave __pycache__ files in its checkout
+
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))

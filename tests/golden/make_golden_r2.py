@@ -21,6 +21,8 @@ train_golden.npz -- the reference's ``train_model`` (src/networks.py:71-99) driv
 """
 import os
 import sys
+
+sys.dont_write_bytecode = True      # importing the reference must not leave __pycache__ files in its checkout
 import tempfile
 import zlib
 
