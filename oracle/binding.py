@@ -39,6 +39,9 @@ def _load():
             fn = getattr(lib, f"oracle_pipeline_{suffix}")
             fn.argtypes = [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, ctypes.c_int]
             fn.restype = None
+            fn = getattr(lib, f"oracle_pipeline_ex_{suffix}")
+            fn.argtypes = [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, ctypes.c_int, ctypes.c_int]
+            fn.restype = None
         lib.oracle_dense_wht_f64.argtypes = [_P, _P, _I64, _I64]
         lib.oracle_dense_wht_f64.restype = None
         _lib = lib
@@ -77,8 +80,10 @@ def fwht_descending(x: np.ndarray) -> np.ndarray:
     return out
 
 
-def pipeline(x, a=None, b=None, c=None, *, n_samples=1, sample_stride=1, group_rows=1, axis="col"):
-    """y = a (.) FWHT(b (.) FWHT(c (.) x)); see fwht_oracle.c:oracle_pipeline_f32."""
+def pipeline(x, a=None, b=None, c=None, *, n_samples=1, sample_stride=1, group_rows=1, axis="col",
+             a_per_sample=False, c_per_sample=False):
+    """y = a (.) FWHT(b (.) FWHT(c (.) x)); see fwht_oracle.c:oracle_pipeline_f32.  ``a_per_sample`` /
+    ``c_per_sample``: the outer vectors are indexed by the row's sample like ``b`` (oracle_pipeline_ex_<type>)."""
     x = np.ascontiguousarray(x)
     assert x.ndim == 2 and x.dtype in (np.float32, np.float64)
     rows, n = x.shape
@@ -91,17 +96,18 @@ def pipeline(x, a=None, b=None, c=None, *, n_samples=1, sample_stride=1, group_r
         assert v.size == length, (v.size, length)
         return v, v.ctypes.data
 
-    if ax == 0:
-        a_, ap = prep(a, group_rows)
-        b_, bp = prep(b, n_samples * group_rows)
-        c_, cp = prep(c, group_rows)
-    else:
-        a_, ap = prep(a, n)
-        b_, bp = prep(b, n_samples * n)
-        c_, cp = prep(c, n)
+    unit = group_rows if ax == 0 else n
+    a_, ap = prep(a, unit * (n_samples if a_per_sample else 1))
+    b_, bp = prep(b, unit * n_samples)
+    c_, cp = prep(c, unit * (n_samples if c_per_sample else 1))
     y = np.empty_like(x)
-    getattr(_load(), "oracle_pipeline_" + _SUFFIX[x.dtype])(
-        y.ctypes.data, x.ctypes.data, ap, bp, cp, rows, n, n_samples, sample_stride, group_rows, ax)
+    if a_per_sample or c_per_sample:
+        getattr(_load(), "oracle_pipeline_ex_" + _SUFFIX[x.dtype])(
+            y.ctypes.data, x.ctypes.data, ap, bp, cp, rows, n, n_samples, sample_stride, group_rows, ax,
+            (1 if a_per_sample else 0) | (2 if c_per_sample else 0))
+    else:
+        getattr(_load(), "oracle_pipeline_" + _SUFFIX[x.dtype])(
+            y.ctypes.data, x.ctypes.data, ap, bp, cp, rows, n, n_samples, sample_stride, group_rows, ax)
     return y
 
 

@@ -11,8 +11,10 @@
  *   - golden fixtures emitted by the live reference (tests/golden/make_golden.py),
  *   - and, when oracle/_ref is built, the reference C++ FWHT itself, bit for bit.
  *
- * Build:  make -C oracle   (gcc -O2 -ffp-contract=off; no fast-math, so every
- * add/sub/mul is one IEEE-754 rounding exactly as the reference's ATen ops).
+ * Build:  make -C oracle   (gcc -O2 -ffp-contract=off -fwrapv; no fast-math, so every
+ * add/sub/mul is one IEEE-754 rounding exactly as the reference's ATen ops, and
+ * integer sums that overflow wrap modulo 2^32 / 2^64 as the reference's integer
+ * tensors do -- pinned against oracle/_ref on overflowing inputs).
  */
 #include <stdint.h>
 #include <stddef.h>
@@ -169,6 +171,44 @@ void oracle_pipeline_f64(double *y, const double *x, const double *a,
                 dst[j] = (axis == 0 ? a[rr] : a[j]) * dst[j];
     }
 }
+
+/*
+ * The same pipeline over batches of INDEPENDENT weight matrices: the sub-matrices
+ * of WHVIStackedMatrix (src/weights.py:130-132,179-180) each carry their own s1 /
+ * s2 / u, so the outer scale vectors are indexed by the row's sample as well --
+ * flags bit 0: a is per sample, bit 1: c is per sample (b always is):
+ *     a[s*group_rows + rr] (axis 0)      a[s*n + j] (axis 1), likewise c.
+ * flags == 0 is oracle_pipeline_<type>.  One multiply = one rounding, as above.
+ */
+#define DEFINE_PIPELINE_EX(NAME, T, FWHT)                                      \
+    void NAME(T *y, const T *x, const T *a, const T *b, const T *c,            \
+              int64_t rows, int64_t n, int64_t n_samples,                      \
+              int64_t sample_stride, int64_t group_rows, int axis, int flags)  \
+    {                                                                          \
+        const int64_t unit = axis == 0 ? group_rows : n;                       \
+        for (int64_t r = 0; r < rows; ++r) {                                   \
+            const T *src = x + r * n;                                          \
+            T *dst = y + r * n;                                                \
+            int64_t s = (r / sample_stride) % n_samples;                       \
+            int64_t rr = r % group_rows;                                       \
+            const T *av = a ? a + ((flags & 1) ? s * unit : 0) : 0;            \
+            const T *bv = b ? b + s * unit : 0;                                \
+            const T *cv = c ? c + ((flags & 2) ? s * unit : 0) : 0;            \
+            for (int64_t j = 0; j < n; ++j)                                    \
+                dst[j] = cv ? cv[axis == 0 ? rr : j] * src[j] : src[j];        \
+            FWHT(dst, 1, n);                                                   \
+            if (bv)                                                            \
+                for (int64_t j = 0; j < n; ++j)                                \
+                    dst[j] = bv[axis == 0 ? rr : j] * dst[j];                  \
+            FWHT(dst, 1, n);                                                   \
+            if (av)                                                            \
+                for (int64_t j = 0; j < n; ++j)                                \
+                    dst[j] = av[axis == 0 ? rr : j] * dst[j];                  \
+        }                                                                      \
+    }
+
+DEFINE_PIPELINE_EX(oracle_pipeline_ex_f32, float, oracle_fwht_f32)
+DEFINE_PIPELINE_EX(oracle_pipeline_ex_f64, double, oracle_fwht_f64)
 
 /* Dense Sylvester-Hadamard entry, H[i][j] = (-1)^popcount(i & j): the closed
  * form of the recursion in src/utils.py:88-101 (build_H_recursive). */

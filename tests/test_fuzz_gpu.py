@@ -73,35 +73,48 @@ def _fused_cases():
         layout = int(rng.integers(0, 2))            # 0: (batch, sample, D)  1: (sample, batch, D)
         B = int(rng.integers(1, 40))
         big = rng.random() < 0.25
-        out.append((i, log2d, S, axis, layout, B * (400 if big else 1)))
+        out.append((i, log2d, S, axis, layout, B * (400 if big else 1), np.float32, 0))
+    # float64 and the per-sample outer vectors (flags bit 0: a, bit 1: c), every third case >= 32 tiles per CU (the tuned
+    # instantiations of dispatch.hpp: launch_fused); drawn from a second stream so the cases above stay what they were
+    rng = np.random.default_rng(78)
+    for i in range(max(18, N_CASES // 2)):
+        dtype = np.float64 if i % 2 else np.float32
+        log2d = int(rng.integers(1 if dtype == np.float64 else 2, 13))
+        S = int(rng.integers(1, 9))
+        axis = "col" if rng.random() < 0.6 else "row"
+        layout = int(rng.integers(0, 2))
+        B = int(rng.integers(1, 40))
+        out.append((100 + i, log2d, S, axis, layout, B * (400 if i % 3 == 0 else 1), dtype, int(rng.integers(0, 4))))
     return out
 
 
-@pytest.mark.parametrize("case,log2d,S,axis,layout,B", _fused_cases())
-def test_random_fused(case, log2d, S, axis, layout, B, hip_lib):
+@pytest.mark.parametrize("case,log2d,S,axis,layout,B,dtype,flags", _fused_cases())
+def test_random_fused(case, log2d, S, axis, layout, B, dtype, flags, hip_lib):
     d = 1 << log2d
     if B * S * d > (1 << 26):
         B = max(1, (1 << 26) // (S * d))
     rng = np.random.default_rng(1000 + case)
     rows = B * S
-    x = rng.standard_normal((rows, d)).astype(np.float32)
+    x = rng.standard_normal((rows, d)).astype(dtype)
     stride = 1 if layout == 0 else B
+    a_ps, c_ps = bool(flags & 1), bool(flags & 2)
     if axis == "col":
-        a, c = rng.standard_normal(d).astype(np.float32), rng.standard_normal(d).astype(np.float32)
-        b = rng.standard_normal((S, d)).astype(np.float32)
+        unit = d
         kw = dict(axis="col", n_samples=S, sample_stride=stride)
     else:
         G = int(rng.choice([1, 3, d, 2 * d + 1]))
         rows = (rows // G) * G or G
-        x = rng.standard_normal((rows, d)).astype(np.float32)
-        a, c = rng.standard_normal(G).astype(np.float32), rng.standard_normal(G).astype(np.float32)
-        b = rng.standard_normal((S, G)).astype(np.float32)
+        x = rng.standard_normal((rows, d)).astype(dtype)
+        unit = G
         stride = G if layout == 1 else 1
         kw = dict(axis="row", n_samples=S, sample_stride=stride, group_rows=G)
-    want = oracle.pipeline(x, a, b, c, **kw)
+    a = rng.standard_normal((S, unit) if a_ps else unit).astype(dtype)
+    c = rng.standard_normal((S, unit) if c_ps else unit).astype(dtype)
+    b = rng.standard_normal((S, unit)).astype(dtype)
+    want = oracle.pipeline(x, a, b, c, a_per_sample=a_ps, c_per_sample=c_ps, **kw)
     t = lambda v: torch.from_numpy(v).to(DEV)   # noqa: E731
-    got = _hip.fused_shs(t(x), t(a), t(b), t(c), **kw).cpu().numpy()
-    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (case, log2d, S, axis, layout, rows)
+    got = _hip.fused_shs(t(x), t(a), t(b), t(c), a_per_sample=a_ps, c_per_sample=c_ps, **kw).cpu().numpy()
+    assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), (case, log2d, S, axis, layout, rows, dtype, flags)
 
 
 def _wbar_cases():

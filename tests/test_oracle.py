@@ -74,6 +74,42 @@ def test_bit_equal_to_compiled_reference():
         assert np.array_equal(ref.forward(xi).numpy(), oracle.fwht(xi.numpy()))
 
 
+def test_integer_overflow_wraps_like_the_reference():
+    """Integer rows whose partial sums leave the type's range (inputs near +/-2^30 resp. +/-2^62, D = 4096: twelve
+    doublings).  The reference's integer tensors wrap (ATen's two's complement add / sub under
+    src/fwht/cpp/fwht.cpp:11-13); the oracle's integer legs are built with -fwrapv, agree with exact arithmetic reduced
+    modulo 2^32 / 2^64, and -- when oracle/_ref is built -- with the reference's own compiled C++ FWHT on the same
+    int32 / int64 tensors, bit for bit.  This is what tests/test_streaming_parity_gpu.py::test_int32_wraps_like_the_reference
+    holds the HIP int32 kernels to."""
+    rng = np.random.default_rng(2 ** 30)
+    d, rows = 4096, 6
+    mag = rng.integers((1 << 30) - 4096, (1 << 30) + 4096, (rows, d))
+    x32 = (mag * rng.choice([-1, 1], (rows, d))).astype(np.int32)
+    got32 = oracle.fwht(x32)
+    exact = oracle.fwht(x32.astype(np.int64))                     # |.| <= 2^42: no overflow in 64 bits
+    assert np.abs(exact).max() > 2 ** 31, "the inputs must make 32-bit sums overflow"
+    assert got32.dtype == np.int32 and np.array_equal(got32, exact.astype(np.int32))
+    # python integers (unbounded) on one row, reduced modulo 2^32
+    row = [int(v) for v in x32[0]]
+    h = 1
+    while h < d:
+        for i in range(0, d, 2 * h):
+            for j in range(i, i + h):
+                row[j], row[j + h] = row[j] + row[j + h], row[j] - row[j + h]
+        h *= 2
+    wrapped = np.array([((v + 2 ** 31) % 2 ** 32) - 2 ** 31 for v in row], dtype=np.int64)
+    assert np.array_equal(got32[0].astype(np.int64), wrapped)
+    x64 = ((mag.astype(np.int64) << 32) * rng.choice([-1, 1], (rows, d))).astype(np.int64)
+    got64 = oracle.fwht(x64)
+    assert np.array_equal(got64[:, 0], np.sum(x64.astype(np.uint64), axis=1, dtype=np.uint64).astype(np.int64))   # y[0] = sum, mod 2^64
+    ref = oracle.load_reference_cpp()
+    if ref is None:
+        pytest.skip("oracle/_ref not built: wrap-around checked against exact arithmetic only")
+    import torch
+    assert np.array_equal(ref.forward(torch.from_numpy(x32)).numpy(), got32)
+    assert np.array_equal(ref.forward(torch.from_numpy(x64)).numpy(), got64)
+
+
 def test_stage_order_tolerance_statement():
     """SURVEY.md finding 3: descending strides (the reference CUDA kernel's order) differ from the
     ascending order only by fp32 rounding, a few 1e-7 * max|y|; identical on integers."""
@@ -114,6 +150,36 @@ def test_pipeline_is_composition_of_primitives():
     for r in range(B * S):
         M = np.diag(c.astype(np.float64)) @ H @ np.diag(b[r % S].astype(np.float64)) @ H @ np.diag(a.astype(np.float64))
         assert np.allclose(got64[r], x64[r] @ M, rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("axis", ["col", "row"])
+def test_per_sample_pipeline_is_the_shared_pipeline_sample_by_sample(axis, dtype):
+    """oracle.pipeline(a_per_sample, c_per_sample) -- the checker of whvi_fused_shs_ex's WHVI_FUSED_{A,C}_PER_SAMPLE flags,
+    i.e. batches of independent weight matrices (src/weights.py:130-132,179-180) -- equals the shared-vector pipeline
+    (pinned above) applied row by row with that row's sample's vectors; both row orders."""
+    rng = np.random.default_rng(5)
+    d, S, B, G = 16, 3, 4, 5
+    rows = B * S * G if axis == "row" else B * S
+    unit = G if axis == "row" else d
+    x = rng.standard_normal((rows, d)).astype(dtype)
+    a, b, c = (rng.standard_normal((S, unit)).astype(dtype) for _ in range(3))
+    for stride in (1, G if axis == "row" else B):
+        y = oracle.pipeline(x, a, b, c, n_samples=S, sample_stride=stride, group_rows=G, axis=axis, a_per_sample=True,
+                            c_per_sample=True)
+        for r in range(rows):
+            s = (r // stride) % S
+            if axis == "col":
+                w = oracle.pipeline(x[r:r + 1], a[s], b[s][None], c[s], n_samples=1, axis="col")[0]
+            else:
+                rr = r % G
+                w = oracle.pipeline(x[r:r + 1], a[s][rr:rr + 1], b[s][rr:rr + 1], c[s][rr:rr + 1], n_samples=1,
+                                    group_rows=1, axis="row")[0]
+            assert np.array_equal(y[r], w), (axis, stride, r)
+        only_a = oracle.pipeline(x, a, b, c[0], n_samples=S, sample_stride=stride, group_rows=G, axis=axis, a_per_sample=True)
+        shared = oracle.pipeline(x, a[0], b, c[0], n_samples=S, sample_stride=stride, group_rows=G, axis=axis)
+        first = ((np.arange(rows) // stride) % S) == 0
+        assert np.array_equal(only_a[first], shared[first])
 
 
 def test_w_bar_collapses_to_diagonal_exactly():
