@@ -75,7 +75,15 @@ int         whvi_max_log2d(int32_t dtype);  /* largest supported log2(D): 24 for
 
 /* Batched row FWHT: dst[r, :] = FWHT(src[r, :]) for r in [0, rows).
  * Replaces fwht_cuda_frontend (fwht_cuda_kernel.cu:156-181) + the X.clone() of
- * fwht_cuda.cpp:11 (pass dst != src for the reference's out-of-place semantics). */
+ * fwht_cuda.cpp:11 (pass dst != src for the reference's out-of-place semantics).
+ *
+ * Sign of zero (f32 only; every other bit of every result, NaN positions included, is independent of the launch form):
+ * the streaming launch of whvi_fwht_f32 for D = 512 .. 2048 (buffers beyond the 256 MiB Infinity Cache) and both fused
+ * pipelines run their lane stages as fused multiply-adds by +/-1, through which a zero carries no sign.  A result that
+ * is NEGATIVE zero in the reference's arithmetic (-0 + -0: element 0 of a row made of negative zeros only) may therefore
+ * come back as +0 from those launches while the cache-resident launch of the same call returns -0; exact cancellations are +0
+ * either way.  Callers that compare raw bits across batch sizes should compare zeros by value
+ * (tests/test_fwht_gpu.py::test_negative_zero_contract_of_both_launch_forms). */
 int whvi_fwht_f32 (void *dst, const void *src, int64_t rows, int32_t log2d, void *stream);
 int whvi_fwht_f64 (void *dst, const void *src, int64_t rows, int32_t log2d, void *stream);
 int whvi_fwht_f16 (void *dst, const void *src, int64_t rows, int32_t log2d, void *stream);
@@ -95,8 +103,14 @@ int whvi_fwht_i32 (void *dst, const void *src, int64_t rows, int32_t log2d, void
  *                 7  as 3 with non-temporal accesses
  *   bits 4..5 : threads per block, 0 = 256, 1 = 512, 2 = 1024 (576 for the LDS-staged network)
  *   bits 8..19: cap of the grid in blocks per CU (0 = uncapped: one tile per wave)
+ *   bits 20..22: launch form of rows LONGER than one wavefront tile (D > 8192; f64 > 4096), every dtype:
+ *                 0  production (a block per row up to D = 65536, pipelined grid chosen by size; pieces + passes beyond)
+ *                 1  2^12-element pieces + high-bit passes for every long row (round 1's form)
+ *                 2  one row per block      3  persistent pipelined grid (where that instantiation exists)
+ *                 4  as 1 with every pass over the whole buffer instead of 128 MiB row groups
  * Variants other than the ds_bpermute cross-check exist for f32 and D = 512..4096 only; elsewhere only
- * bit 0 is honoured.  All variants produce identical bits (tests/test_fwht_gpu.py).
+ * bit 0 (and bits 20..22) are honoured.  All variants produce identical bits (tests/test_fwht_gpu.py).
+ * The library reads NO environment variables: its launch form is a function of its arguments.
  */
 int whvi_fwht_ex(void *dst, const void *src, int64_t rows, int32_t log2d,
                  int32_t dtype, int32_t variant, void *stream);

@@ -32,6 +32,29 @@ def test_library_exports_every_declared_symbol():
     assert _hip.lib().whvi_hip_abi_version() == 1
 
 
+def test_shipped_library_reads_no_environment():
+    """A library a maintainer links must not change its launch form with the caller's environment: the shipped build
+    (no -DWHVI_TUNING_BUILD, whvi_amd/csrc/tuning.hpp) contains no WHVI_* switch name, does not import getenv, and the
+    product Makefile target never defines the macro.  Measurement builds live apart (make tuning -> whvi_amd/_exp/)."""
+    import subprocess
+    from whvi_amd import _hip
+    default_lib = os.path.join(ROOT, "whvi_amd", "libwhvi_hip.so")
+    assert os.path.exists(default_lib)
+    strings = subprocess.run(["strings", "-a", default_lib], capture_output=True, text=True, check=True).stdout
+    hits = sorted({ln.strip() for ln in strings.splitlines() if re.search(r"WHVI_[A-Z0-9_]+", ln)})
+    assert hits == [], hits
+    imports = subprocess.run(["nm", "-D", "--undefined-only", default_lib], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in imports
+    mk = open(os.path.join(ROOT, "whvi_amd", "csrc", "Makefile")).read()
+    product = mk.split("tuning:")[0]
+    assert "WHVI_TUNING_BUILD" not in re.sub(r"#.*", "", product)
+    # every run-time switch of the sources goes through the one macro that is a null pointer in the shipped build
+    for name in os.listdir(os.path.join(ROOT, "whvi_amd", "csrc")):
+        if name.endswith((".hpp", ".hip")) and name != "tuning.hpp":
+            text = open(os.path.join(ROOT, "whvi_amd", "csrc", name)).read()
+            assert "getenv" not in text, name
+
+
 def test_argument_checks_without_gpu():
     from whvi_amd import _hip
     L = _hip.lib()

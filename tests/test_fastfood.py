@@ -205,3 +205,29 @@ def test_small_widths_cpu(monkeypatch):
 @pytest.mark.gpu
 def test_small_widths_gpu(monkeypatch, hip_lib):
     run_small_widths("cuda", monkeypatch)
+
+
+@pytest.mark.gpu
+def test_layers_wider_than_the_fused_kernel_gpu(monkeypatch, hip_lib):
+    """the constructor accepts any power of two but ``whvi_fused_shs`` stops at one wavefront tile
+    (D = 8192); a D = 16384 layer used to build and then fail at its first forward.  It now runs the same multiplies and
+    butterflies as separate launches (``fwht_rows``: a block per row) -- bit-exact against the same oracle, forward and
+    backward both usable."""
+    from whvi_amd import _hip
+    D, S, B = 16384, 2, 3
+    assert not _hip.fused_supported(torch.float32, D) and _hip.fused_supported(torch.float32, 8192)
+    layer = _layer(D, seed=3, bias=False).to("cuda")
+    sub = layer.weight_submodule
+    rng = np.random.default_rng(6)
+    x = rng.standard_normal((B, D)).astype(np.float32)
+    eps = rng.standard_normal((S, D)).astype(np.float32)
+    monkeypatch.setattr(torch, "randn", ReplayRandn([eps]))
+    xt = torch.from_numpy(x).to("cuda").requires_grad_()
+    y = layer.forward_mc(xt, S)
+    monkeypatch.undo()
+    g = (sub.g_mu + sub.g_sigma * torch.from_numpy(eps).to("cuda")).detach().cpu().numpy()
+    want = oracle.pipeline(np.tile(x, (S, 1)), sub.s1.detach().cpu().numpy(), g, sub.s2.detach().cpu().numpy(),
+                           n_samples=S, sample_stride=B, axis="col").reshape(S, B, D)
+    assert np.array_equal(_bits(y.detach().cpu().numpy()), _bits(want))
+    y.square().mean().backward()
+    assert bool(torch.isfinite(xt.grad).all()) and all(bool(torch.isfinite(p.grad).all()) for p in sub.parameters())

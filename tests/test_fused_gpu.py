@@ -391,6 +391,37 @@ def test_reparam_kl_kernel_vs_torch_ops(hip_lib):
         assert torch.allclose(a_, b_, rtol=1e-4, atol=1e-5 * float(b_.abs().max()))
 
 
+def test_kl_property_tolerance_contract(hip_lib):
+    """``layer.kl`` on the GPU in float32 is one launch of the reparameterisation + KL kernel: the same D terms as
+    ``kl_diag_normal`` (src/utils.py:49-71, the reference's argument convention) in another summation order.  Contract
+    (weights._posterior_kl): equal to the formula evaluated as torch ops within 2e-6 relative -- not bit for bit -- for
+    every layer flavour; float64 parameters evaluate the formula itself, bit for bit; lambda <= 0 raises."""
+    from whvi_amd.utils import kl_diag_normal
+    torch.manual_seed(21)
+    for n_in, n_out in ((512, 512), (4096, 4096), (3, 1024), (1024, 1), (1, 10)):
+        layer = WHVILinear(n_in, n_out, lambda_=0.37).to(DEV)
+        want = 0.0
+        with torch.no_grad():
+            for m in layer.modules():
+                if type(m).__name__ in ("WHVISquarePow2Matrix", "_PackedSubMatrix"):
+                    m.g_mu.normal_(0.0, 0.5)
+                    sd = torch.nn.functional.softplus(m.g_rho).double()
+                    want = want + kl_diag_normal(m.g_mu.double(), sd, torch.zeros_like(sd), torch.full_like(sd, 0.37))
+        got = layer.kl
+        assert got.dtype == torch.float32 and abs(float(got) - float(want)) <= 2e-6 * abs(float(want)), (n_in, n_out)
+        f64 = layer.double()
+        formula = sum(kl_diag_normal(m.g_mu, torch.nn.functional.softplus(m.g_rho), torch.zeros_like(m.g_mu),
+                                     torch.ones_like(m.g_mu) * 0.37)
+                      for m in f64.modules() if type(m).__name__ == "WHVISquarePow2Matrix")
+        if (n_in, n_out) == (3, 1024):       # stacked: one formula evaluation over all 256 sub-matrices instead of 256 sums
+            assert abs(float(f64.kl) - float(formula)) <= 1e-12 * abs(float(formula))
+        else:
+            assert torch.equal(f64.kl, formula), "float64: the reference's formula itself"
+    bad = WHVILinear(8, 8, lambda_=0.0).to(DEV)
+    with pytest.raises(RuntimeError, match="lambda must be positive"):
+        bad.kl
+
+
 def test_graphed_train_step_learns(hip_lib):
     """Whole-step hipGraph replay (loss + backward through the fused kernels + Adam): the fit improves and the
     variational parameters move."""

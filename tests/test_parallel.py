@@ -110,6 +110,38 @@ def _worker(rank, world, port, tmp):
         dist.destroy_process_group()
 
 
+def test_inkernel_rng_is_reseeded_in_place_and_restored():
+    """a captured hipGraph has the Philox state tensor's address baked in, so re-seeding must write INTO the
+    existing tensor (never replace it), and an evaluation pass must hand the training stream back where it was --
+    otherwise every training step after an evaluation with the same base_seed would repeat the same eps."""
+    import torch.nn as nn
+    from whvi_amd.layers import WHVILinear
+    from whvi_amd.networks import WHVIRegression
+    net = WHVIRegression([WHVILinear(3, 8), nn.ReLU(), WHVILinear(8, 8), nn.ReLU(), WHVILinear(8, 1)])
+    net.set_inkernel_rng()
+    assert parallel.seed_inkernel_rng(net, base_seed=3) >= 3
+    mods = [m for m in net.modules() if getattr(m, "_rng_state", None) is not None]
+    ptrs = [m._rng_state.data_ptr() for m in mods]
+    first = [m._rng_state.clone() for m in mods]
+    for m in mods:
+        m._rng_state[1] += 17                                  # "training has advanced the offset"
+    parallel.seed_inkernel_rng(net, base_seed=4)
+    assert [m._rng_state.data_ptr() for m in mods] == ptrs, "re-seeding must not replace the state tensor"
+    assert all(int(m._rng_state[1]) == 0 and int(m._rng_state[0]) != int(f[0]) for m, f in zip(mods, first))
+    # an evaluation pass re-seeds inside and restores on exit: same tensors, same values as before the call
+    for m in mods:
+        m._rng_state[1] += 5
+    before = [m._rng_state.clone() for m in mods]
+    pred = parallel.mc_sharded_forward(net, torch.randn(4, 3), n_samples=3, base_seed=9)
+    assert pred.shape == (4, 1, 3)
+    assert [m._rng_state.data_ptr() for m in mods] == ptrs
+    assert all(torch.equal(m._rng_state, b) for m, b in zip(mods, before))
+    # a layer that had no state yet has none afterwards (the training stream draws its own seed on first use)
+    net.set_inkernel_rng()
+    parallel.mc_sharded_forward(net, torch.randn(4, 3), n_samples=2, base_seed=9)
+    assert all(getattr(m, "_rng_state", None) is None for m in net.modules())
+
+
 def test_world_size_2_gloo(tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)

@@ -89,6 +89,37 @@ def test_mc_sharded_forward_and_grad_all_reduce(rccl_group):
             assert torch.equal(p.grad, g)                 # average over one rank
 
 
+def test_graph_survives_an_evaluation_pass_with_the_inkernel_rng(rccl_group):
+    """``mc_sharded_forward`` used to REPLACE every layer's Philox state tensor; a hipGraph captured
+    before it kept launching with the old tensor's address (freed by then).  Now the state is re-seeded in place and
+    restored: the graph's tensor is still the layer's tensor, its offset keeps advancing across replays, and the
+    training stream continues where it was instead of restarting at offset 0 after every evaluation."""
+    from whvi_amd.graphs import GraphedPredictor
+    dev = rccl_group
+    torch.manual_seed(4)
+    net = WHVIRegression([WHVILinear(3, 16), nn.ReLU(), WHVILinear(16, 16), nn.ReLU(), WHVILinear(16, 1)]).to(dev)
+    net.set_inkernel_rng()
+    x = torch.randn(9, 3, device=dev)
+    graphed = GraphedPredictor(net, x, n_samples=4)
+    mods = [m for m in net.modules() if getattr(m, "_rng_state", None) is not None]
+    assert len(mods) >= 3
+    ptrs = [m._rng_state.data_ptr() for m in mods]
+    first = graphed(x).clone()
+    torch.cuda.synchronize()
+    offsets = [int(m._rng_state[1]) for m in mods]
+    assert all(o > 0 for o in offsets)
+    a = parallel.mc_sharded_forward(net, x, n_samples=6, base_seed=1)
+    b = parallel.mc_sharded_forward(net, x, n_samples=6, base_seed=1)
+    assert torch.equal(a, b)                                             # evaluation is still reproducible
+    assert [m._rng_state.data_ptr() for m in mods] == ptrs, "the state tensors a graph points at must stay"
+    assert [int(m._rng_state[1]) for m in mods] == offsets, "the training stream continues where it was"
+    second = graphed(x).clone()
+    torch.cuda.synchronize()
+    assert all(int(m._rng_state[1]) > o for m, o in zip(mods, offsets)), "the replay advanced the live state"
+    assert not torch.equal(first, second) and bool(torch.isfinite(second).all())
+    net.set_inkernel_rng(False)
+
+
 def test_bench_multi_gpu_phases_small(rccl_group):
     """bench.py's N > 1 phases (config 5 row shards, config 4 MC-sharded pass with its all-gather) at test sizes."""
     import bench

@@ -1,12 +1,15 @@
 """tools/probe_block_trace.py [log2d] [dtype] -- per-row timeline of fwht_block_rows_kernel: when wave 0 of the block
 started on the row, had its tile transformed, finished the LDS exchange and issued its stores, and on which CU it ran.
-Needs the traced build of the library (the production kernels carry no stamps):
-    make -C whvi_amd/csrc OBJDIR=/tmp/whvi_trace OUT=../_exp/libwhvi_hip_trace.so DEFS=-DWHVI_BLOCK_TRACE ../_exp/libwhvi_hip_trace.so
-    WHVI_HIP_LIB=whvi_amd/_exp/libwhvi_hip_trace.so [WHVI_BLOCK_PIPE=0|1] python tools/probe_block_trace.py 16 float32
+Needs the traced build of the library (the production kernels carry no stamps); tools/_tuning.py builds it
+(make -C whvi_amd/csrc tuning TAG=trace DEFS=-DWHVI_BLOCK_TRACE -> whvi_amd/_exp/libwhvi_hip_trace.so) and loads it:
+    python tools/probe_block_trace.py 16 float32 [0|1]      (third argument: one row per block / pipelined grid)
 Prints the average phase lengths and, per CU, the gap between one row's last stamp and the next row's first."""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _tuning  # noqa: E402  (tools/_tuning.py: the environment switches exist in measurement builds only)
+_tuning.use("trace", "-DWHVI_BLOCK_TRACE")
 import numpy as np
 import torch
 
@@ -20,16 +23,17 @@ os.environ["WHVI_BLOCK_TRACE"] = hex(trace.data_ptr())
 from whvi_amd import _hip  # noqa: E402
 
 if "trace" not in os.path.basename(_hip.LIB_PATH):
-    sys.exit("set WHVI_HIP_LIB to the traced build (see the docstring)")
+    sys.exit("the traced build was not loaded (see the docstring)")
+VARIANT = {None: None, "0": 2 << 20, "1": 3 << 20}[sys.argv[3] if len(sys.argv) > 3 else None]
 x = (torch.randn(rows, d, device="cuda") * 0.25).to(dtype)
 for it in range(3):
-    _hip.fwht_rows(x, out=x)
+    _hip.fwht_rows(x, out=x, variant=VARIANT)
     if dtype.is_floating_point:
         x.mul_(2.0 ** (-(log2d // 2)))
 torch.cuda.synchronize()
 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 s.record()
-_hip.fwht_rows(x, out=x)
+_hip.fwht_rows(x, out=x, variant=VARIANT)
 e.record()
 torch.cuda.synchronize()
 print(f"{_hip.last_kernel()}  {s.elapsed_time(e):.3f} ms, {2 * x.numel() * esize / s.elapsed_time(e) / 1e9:.2f} TB/s (with the stamps)")

@@ -1,6 +1,8 @@
 """tools/probe_long_rows.py [GiB] -- rows longer than one wavefront tile, in place on a 4 GiB buffer, HIP-event timed.
-Run twice for the A/B:   python tools/probe_long_rows.py            (production: one block per row up to D = 65536)
-                         WHVI_LONG_ROWS=passes python tools/probe_long_rows.py   (round 1: 4096-element pieces + high-bit passes)
+Run twice for the A/B:   python tools/probe_long_rows.py 4            (production: one block per row up to D = 65536)
+                         python tools/probe_long_rows.py 4 passes     (round 1: 4096-element pieces + high-bit passes; also
+                         "ungrouped": the same with every pass over the whole buffer) -- selected through bits 20..22 of
+                         whvi_fwht_ex's variant word, not through the environment.
 Data stay finite: every launch is followed by an untimed rescale."""
 import os
 import sys
@@ -9,11 +11,12 @@ import torch
 from whvi_amd import _hip
 
 gib = float(sys.argv[1]) if len(sys.argv) > 1 else 4.0
-mode = os.environ.get("WHVI_LONG_ROWS", "block")
+mode = sys.argv[2] if len(sys.argv) > 2 else "block"
+variant = {"block": None, "passes": 1 << 20, "ungrouped": 4 << 20}[mode]
 cases = [(torch.float32, l) for l in (12, 13, 14, 15, 16, 17, 20)] + [(torch.float64, l) for l in (12, 13, 14, 15, 16)] + \
         [(torch.float16, l) for l in (12, 13, 14, 15, 16)] + [(torch.bfloat16, 16), (torch.int32, 16)]
 for dtype, log2d in cases:
-    if mode == "passes" and dtype in (torch.float16, torch.bfloat16) and log2d > 13:
+    if mode != "block" and dtype in (torch.float16, torch.bfloat16) and log2d > 13:
         continue                                    # no multi-pass form for 16-bit storage
     d = 1 << log2d
     esize = torch.empty(0, dtype=dtype).element_size()
@@ -26,7 +29,7 @@ for dtype, log2d in cases:
     for it in range(8):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
-        _hip.fwht_rows(x, out=x)
+        _hip.fwht_rows(x, out=x, variant=variant)
         e.record()
         torch.cuda.synchronize()
         times.append(s.elapsed_time(e))

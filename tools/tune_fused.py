@@ -3,6 +3,9 @@
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _tuning  # noqa: E402  (tools/_tuning.py: the environment switches exist in measurement builds only)
+_tuning.use()
 import torch
 from whvi_amd import _hip
 

@@ -203,6 +203,14 @@ def fwht_rows(src: torch.Tensor, out: torch.Tensor = None, variant: int = None) 
 FUSED_A_PER_SAMPLE, FUSED_C_PER_SAMPLE = 1, 2
 
 
+def fused_supported(dtype: torch.dtype, d: int) -> bool:
+    """Row lengths ``whvi_fused_shs_*`` covers: one wavefront tile, D <= 8192 (f32) / 4096 (f64).  Longer rows have the
+    plain transform only (``fwht_rows``: a block per row, then passes)."""
+    if dtype == torch.float32:
+        return 1 <= d <= 8192
+    return dtype == torch.float64 and 1 <= d <= 4096
+
+
 def fused_shs(src, a=None, b=None, c=None, *, axis: str = "col", n_samples: int = 1,
               sample_stride: int = 1, group_rows: int = 1, rows: int = None, d: int = None,
               dtype=None, device=None, out: torch.Tensor = None, a_per_sample: bool = False,

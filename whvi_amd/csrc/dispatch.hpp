@@ -163,7 +163,7 @@ inline void launch_rows(void *dst, const void *src, int64_t n_chunks, int varian
                 // 6.33 vs 6.24 TB/s for 1024-thread blocks without the barrier (with it, 1024-thread blocks
                 // fall to 5.7: their waves share SIMDs and leave the butterflies microseconds apart); fp16 5.5 ->
                 // 6.2, bf16 5.0 -> 6.1, i32 5.8 -> 6.3 TB/s (tools/probe_stream_blocks.py)
-                static const bool exp_big_blocks = getenv("WHVI_STREAM_BIG_BLOCKS") != nullptr;   // A/B switch
+                static const bool exp_big_blocks = WHVI_TUNE_ENV("WHVI_STREAM_BIG_BLOCKS") != nullptr;   // A/B switch (tuning builds)
                 if (exp_big_blocks || sizeof(T) == 8) WHVI_LAUNCH(POLICY_DPP, false, true, BIG);   // f64, 16 KiB tiles: 6.07 vs 5.93
                 else if constexpr (sizeof(T) == 2 && K * Elem<T>::VEC == 64)
                     // 16-bit storage: half the bytes per butterfly, so the DPP network's VALU time co-limits the
@@ -270,8 +270,11 @@ inline void launch_rows(void *dst, const void *src, int64_t n_chunks, int varian
 }
 
 // One block of 2^LOG2W waves per row of 2^(LOW + LOG2W) elements (kernels.hpp: fwht_block_rows_kernel).
+// form (whvi_fwht_ex variant bits 20..22, cross-checks): 0 = chosen by size, LONG_ONE_ROW = one row per block, LONG_PIPE =
+// the persistent pipelined grid (where the instantiation exists and every resident block has a row)
+constexpr int LONG_PASSES = 1, LONG_ONE_ROW = 2, LONG_PIPE = 3, LONG_PASSES_UNGROUPED = 4;
 template <typename T, int LOG2W>
-inline void launch_block_rows(void *dst, const void *src, int64_t n_rows, hipStream_t st)
+inline void launch_block_rows(void *dst, const void *src, int64_t n_rows, int form, hipStream_t st)
 {
     constexpr int W = 1 << LOG2W;
     constexpr size_t smem = (size_t)W * 8 * 1024;
@@ -279,7 +282,7 @@ inline void launch_block_rows(void *dst, const void *src, int64_t n_rows, hipStr
     const bool nt = stream_sized((n_rows << (LOW + LOG2W)) * (int64_t)sizeof(T), dst, src);
 #ifdef WHVI_BLOCK_TRACE
     // probe builds: WHVI_BLOCK_TRACE=<device pointer, hex> receives 8 x uint64 per row (tools/probe_block_trace.py)
-    static const uintptr_t trace_env = [] { const char *e = getenv("WHVI_BLOCK_TRACE"); return e ? (uintptr_t)strtoull(e, nullptr, 16) : (uintptr_t)0; }();
+    static const uintptr_t trace_env = [] { const char *e = WHVI_TUNE_ENV("WHVI_BLOCK_TRACE"); return e ? (uintptr_t)strtoull(e, nullptr, 16) : (uintptr_t)0; }();
     uint64_t *trace = (uint64_t *)trace_env;
 #else
     uint64_t *trace = nullptr;
@@ -289,8 +292,8 @@ inline void launch_block_rows(void *dst, const void *src, int64_t n_rows, hipStr
     // blocks f32 5.68 -> 5.95, f64 5.71 -> 5.89; 8-wave blocks lose 2 % (two blocks per CU already overlap each other);
     // 16-bit storage loses 20 % at 4 / 8 waves and gains nothing at 16 (half the bytes per butterfly: those rows are bound
     // by the exchange, not by HBM), so it has no pipelined instantiations; neither has f64 at 16 waves, which needs 10
-    // registers more than a 1024-thread block has.  WHVI_BLOCK_PIPE=0 / 1 forces the choice where both forms exist (A/B).
-    static const int pipe_env = [] { const char *e = getenv("WHVI_BLOCK_PIPE"); return e ? atoi(e) : -1; }();
+    // registers more than a 1024-thread block has.  `form` (whvi_fwht_ex) forces the choice where both forms exist (A/B).
+    const int pipe_env = form == LONG_ONE_ROW ? 0 : (form == LONG_PIPE ? 1 : -1);
     const int resident = num_cu() * (16 / W);                        // blocks the chip holds at once (16 waves per CU)
     constexpr bool HAS_PIPE = sizeof(T) == 4 || (sizeof(T) == 8 && W < 16);
     const bool pipe = HAS_PIPE && (pipe_env >= 0 ? (pipe_env != 0 && n_rows > resident) : (W != 8 && n_rows >= 4 * (int64_t)resident));
@@ -324,16 +327,19 @@ inline int fwht_dispatch(void *dst, const void *src, int64_t rows, int32_t log2d
     constexpr int VEC = Elem<T>::VEC;
     const int64_t n_chunks = elems / VEC;   // whole 16-byte chunks
     const int64_t tail_elems = elems - n_chunks * VEC;
-    // WHVI_LONG_ROWS=passes: the round-1 path (2^LOW-element pieces + high-bit passes) for every long row, an A/B switch
-    static const bool passes_only = [] { const char *e = getenv("WHVI_LONG_ROWS"); return e && !strcmp(e, "passes"); }();
+    // variant bits 20..22 (whvi_fwht_ex): launch form of rows longer than one wave tile, for cross-checks and A/Bs --
+    // LONG_PASSES: the round-1 path (2^LOW-element pieces + high-bit passes) for every long row
+    const int long_form = (variant >> 20) & 7;
+    variant &= 0xFFFFF;
+    const bool passes_only = long_form == LONG_PASSES || long_form == LONG_PASSES_UNGROUPED;
     const bool block_rows = log2d > max_single_pass_log2d<T>() && !(passes_only && sizeof(T) != 2);
     // (Rows of exactly two tiles -- f32 / i32 D = 8192, f64 D = 4096 -- stay with one 128-VGPR tile per wave: as 2-wave
     // blocks f32 gains 4 % (5.58 -> 5.80 TB/s), i32 loses 5 % (6.07 -> 5.74), f64 loses 1.5 %; profiles/r02/block_rows_w2.log.)
     if (block_rows && log2d <= max_block_log2d<T>()) {
         switch (log2d - multi_pass_low_log2d<T>()) {
-        case 2: launch_block_rows<T, 2>(dst, src, rows, st); break;
-        case 3: launch_block_rows<T, 3>(dst, src, rows, st); break;
-        default: launch_block_rows<T, 4>(dst, src, rows, st); break;
+        case 2: launch_block_rows<T, 2>(dst, src, rows, long_form, st); break;
+        case 3: launch_block_rows<T, 3>(dst, src, rows, long_form, st); break;
+        default: launch_block_rows<T, 4>(dst, src, rows, long_form, st); break;
         }
         return after_launch("fwht (block rows)");
     }
@@ -342,15 +348,12 @@ inline int fwht_dispatch(void *dst, const void *src, int64_t rows, int32_t log2d
         // a block each, unless the switch above asks for single tiles), passes 2.. = bits [low, log2d), up to HBMAX at a
         // time, in place on dst.  The passes run over row groups of <= 128 MiB one after the other, with cached
         // accesses, so every pass after the first finds its input in the 256 MiB Infinity Cache and HBM sees about one
-        // read and one write of the data (WHVI_PASS_CHUNK_MIB: group size, 0 = whole buffer per pass as in round 1).
+        // read and one write of the data (LONG_PASSES_UNGROUPED: the whole buffer per pass, as in round 1).
         constexpr int LOW = multi_pass_low_log2d<T>();
         const int low = block_rows ? max_block_log2d<T>() : LOW;
         constexpr int HBMAX = 4;                               // 2^4 chunks = 64 accumulator VGPRs per thread
         constexpr int LV = ilog2(VEC);
-        static const int64_t group_bytes = [] {
-            const char *e = getenv("WHVI_PASS_CHUNK_MIB");
-            return (int64_t)(e ? atoll(e) : 128) << 20;
-        }();
+        const int64_t group_bytes = long_form == LONG_PASSES_UNGROUPED ? 0 : (int64_t)128 << 20;
         const int64_t row_bytes = (int64_t)sizeof(T) << log2d;
         int64_t group_rows = group_bytes > 0 ? group_bytes / row_bytes : rows;
         if (group_rows < 1) group_rows = 1;
@@ -359,7 +362,7 @@ inline int fwht_dispatch(void *dst, const void *src, int64_t rows, int32_t log2d
             char *gd = (char *)dst + r0 * row_bytes;
             const char *gs = (const char *)src + r0 * row_bytes;
             const int64_t g_chunks = (n << log2d) / VEC;
-            if (block_rows) launch_block_rows<T, 4>(gd, gs, (n << log2d) >> low, st);
+            if (block_rows) launch_block_rows<T, 4>(gd, gs, (n << log2d) >> low, long_form, st);
             else launch_rows<T, LOW, pick_k<T, LOW>(), false>(gd, gs, g_chunks, 0, st);
             for (int b0 = low; b0 < log2d;) {
                 const int hb = (log2d - b0 < HBMAX) ? (log2d - b0) : HBMAX;
@@ -439,9 +442,10 @@ inline void launch_fused(void *dst, const void *src, const void *a, const void *
     // network ties the DPP one (the kernel is bound by its 4x load-instruction stream, not by VALU):
     //   dpp/256/nt/staged 5.05 TB/s | lds/256 5.00 | dpp/256 4.70 | dpp/512/nt 4.04 | lds/512/nt 4.40
     //   (one 8 KiB row per wave at D = 2048 -- 106 VGPRs, twice the waves -- ties at 4.87; 1024-thread blocks 4.4)
-    // WHVI_FUSED_TUNE=<policy 0|2><block 2|5 (unused: always 256)><nt 0|1><stage 0|1> overrides (read once).
+    // Tuning builds only: WHVI_FUSED_TUNE=<policy 0|2><block 2|5 (unused: always 256)><nt 0|1><stage 0|1> overrides (read once).
+#ifdef WHVI_TUNING_BUILD
     static const char *tune_env = [] {          // ignored unless it is exactly four digits: never read past the NUL
-        const char *e = getenv("WHVI_FUSED_TUNE");
+        const char *e = WHVI_TUNE_ENV("WHVI_FUSED_TUNE");
         if (e == nullptr || strlen(e) != 4) return (const char *)nullptr;
         for (int i = 0; i < 4; ++i)
             if (e[i] < '0' || e[i] > '9') return (const char *)nullptr;
@@ -451,6 +455,29 @@ inline void launch_fused(void *dst, const void *src, const void *a, const void *
     const int t_nt = tune_env ? tune_env[2] - '0' : (nt ? 1 : 0);
     const int t_stg = tune_env ? tune_env[3] - '0' : 1;
     (void)t_pol; (void)t_nt; (void)t_stg;
+#endif
+#ifdef WHVI_TUNING_BUILD
+#define WHVI_FUSED_F32_SHARED(AX, EYE)                                                                  \
+    do {                                                                                                \
+        const int key = (t_pol == 2 ? 4 : 0) | (t_nt ? 2 : 0) | (t_stg ? 1 : 0);                        \
+        switch (key) {                                                                                  \
+        case 0: WHVI_FUSED(AX, EYE, false, 256, POLICY_DPP, false); break;                              \
+        case 1: WHVI_FUSED(AX, EYE, false, 256, POLICY_DPP, true); break;                               \
+        case 2: WHVI_FUSED(AX, EYE, true, 256, POLICY_DPP, false); break;                               \
+        case 3: WHVI_FUSED(AX, EYE, true, 256, POLICY_DPP, true); break;                                \
+        case 4: WHVI_FUSED(AX, EYE, false, 256, POLICY_LDS, false); break;                              \
+        case 5: WHVI_FUSED(AX, EYE, false, 256, POLICY_LDS, true); break;                               \
+        case 6: WHVI_FUSED(AX, EYE, true, 256, POLICY_LDS, false); break;                               \
+        default: WHVI_FUSED(AX, EYE, true, 256, POLICY_LDS, true); break;                               \
+        }                                                                                               \
+    } while (0)
+#else      /* production: DPP network, shared a / c staged in LDS */
+#define WHVI_FUSED_F32_SHARED(AX, EYE)                                                                  \
+    do {                                                                                                \
+        if (nt) WHVI_FUSED(AX, EYE, true, 256, POLICY_DPP, true);                                       \
+        else WHVI_FUSED(AX, EYE, false, 256, POLICY_DPP, true);                                         \
+    } while (0)
+#endif
 #define WHVI_FUSED_GEOM(AX, EYE)                                                                        \
     do {                                                                                                \
         if constexpr (SMALL_TILE && AX == WHVI_AXIS_COL && !(EYE) && sizeof(T) == 8 &&                  \
@@ -464,17 +491,7 @@ inline void launch_fused(void *dst, const void *src, const void *a, const void *
         if constexpr (SMALL_TILE && AX == WHVI_AXIS_COL && !(EYE) && LDS_OK && sizeof(T) == 4 &&        \
                       LOG2D >= 9 && LOG2D <= 12) {                                                      \
             if (big && flags == 0) {                                                                    \
-                const int key = (t_pol == 2 ? 4 : 0) | (t_nt ? 2 : 0) | (t_stg ? 1 : 0);                \
-                switch (key) {                                                                          \
-                case 0: WHVI_FUSED(AX, EYE, false, 256, POLICY_DPP, false); break;                      \
-                case 1: WHVI_FUSED(AX, EYE, false, 256, POLICY_DPP, true); break;                       \
-                case 2: WHVI_FUSED(AX, EYE, true, 256, POLICY_DPP, false); break;                       \
-                case 3: WHVI_FUSED(AX, EYE, true, 256, POLICY_DPP, true); break;                        \
-                case 4: WHVI_FUSED(AX, EYE, false, 256, POLICY_LDS, false); break;                      \
-                case 5: WHVI_FUSED(AX, EYE, false, 256, POLICY_LDS, true); break;                       \
-                case 6: WHVI_FUSED(AX, EYE, true, 256, POLICY_LDS, false); break;                       \
-                default: WHVI_FUSED(AX, EYE, true, 256, POLICY_LDS, true); break;                       \
-                }                                                                                       \
+                WHVI_FUSED_F32_SHARED(AX, EYE);                                                         \
                 break;                                                                                  \
             }                                                                                           \
         }                                                                                               \
@@ -485,6 +502,7 @@ inline void launch_fused(void *dst, const void *src, const void *a, const void *
     else if (axis == WHVI_AXIS_ROW) WHVI_FUSED_GEOM(WHVI_AXIS_ROW, false);
     else WHVI_FUSED_GEOM(WHVI_AXIS_COL, false);
 #undef WHVI_FUSED_GEOM
+#undef WHVI_FUSED_F32_SHARED
 #undef WHVI_FUSED
 }
 

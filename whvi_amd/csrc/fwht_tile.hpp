@@ -33,6 +33,8 @@
 #include <stdint.h>
 #include <type_traits>
 
+#include "tuning.hpp"
+
 namespace whvi {
 
 constexpr int POLICY_DPP = 0;

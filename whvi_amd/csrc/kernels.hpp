@@ -18,6 +18,7 @@
 #include <string.h>
 
 #include "../../include/whvi_hip.h"
+#include "tuning.hpp"
 #include "fwht_tile.hpp"
 
 namespace whvi {
@@ -96,44 +97,48 @@ template <> struct Elem<__half> {
         // v_cvt_f32_f16_sdwa (src0_sel:WORD_1), and the stream runs 2.6 % slower: 6.21 vs 6.37 TB/s at D = 4096, 2^20 rows,
         // interleaved A/B on identical finite data (tools/probe_f16_convert.py, profiles/r02/f16_convert_ab.log; with
         // bf16's bit moves in place of the converts -- wrong values, timing only -- 6.41).  Same values either way.
-#ifndef WHVI_F16_UNPACK
-#define WHVI_F16_UNPACK 1
-#endif
-#if WHVI_F16_UNPACK == 2   /* timing experiment only: bf16's bit moves (wrong values) */
+#if WHVI_F16_UNPACK == 1
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float lo, hi;
+            uint32_t sh;
+            asm("v_cvt_f32_f16 %0, %1" : "=v"(lo) : "v"(raw[i]));
+            asm("v_lshrrev_b32 %0, 16, %1" : "=v"(sh) : "v"(raw[i]));
+            asm("v_cvt_f32_f16 %0, %1" : "=v"(hi) : "v"(sh));
+            o[2 * i] = lo;
+            o[2 * i + 1] = hi;
+        }
+#elif defined(WHVI_TUNING_BUILD) && WHVI_F16_UNPACK == 2   /* timing experiment only: bf16's bit moves (WRONG values) */
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const uint32_t u = raw[i];
             o[2 * i] = __uint_as_float(u << 16);
             o[2 * i + 1] = __uint_as_float(u & 0xFFFF0000u);
         }
-#elif WHVI_F16_UNPACK == 1 || WHVI_F16_UNPACK == 3
-#if WHVI_F16_UNPACK == 3
-#define WHVI_F16_ASM asm volatile
-#else
-#define WHVI_F16_ASM asm
-#endif
+#elif defined(WHVI_TUNING_BUILD) && WHVI_F16_UNPACK == 3   /* the production form as volatile asm */
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float lo, hi;
             uint32_t sh;
-            WHVI_F16_ASM("v_cvt_f32_f16 %0, %1" : "=v"(lo) : "v"(raw[i]));
-            WHVI_F16_ASM("v_lshrrev_b32 %0, 16, %1" : "=v"(sh) : "v"(raw[i]));
-            WHVI_F16_ASM("v_cvt_f32_f16 %0, %1" : "=v"(hi) : "v"(sh));
+            asm volatile("v_cvt_f32_f16 %0, %1" : "=v"(lo) : "v"(raw[i]));
+            asm volatile("v_lshrrev_b32 %0, 16, %1" : "=v"(sh) : "v"(raw[i]));
+            asm volatile("v_cvt_f32_f16 %0, %1" : "=v"(hi) : "v"(sh));
             o[2 * i] = lo;
             o[2 * i + 1] = hi;
         }
-#undef WHVI_F16_ASM
-#else   /* 0: the compiler's form (SDWA operand for the high half) */
+#elif defined(WHVI_TUNING_BUILD)   /* 0: the compiler's form (SDWA operand for the high half) */
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             o[2 * i] = __half2float(__ushort_as_half((unsigned short)(raw[i] & 0xFFFFu)));
             o[2 * i + 1] = __half2float(__ushort_as_half((unsigned short)(raw[i] >> 16)));
         }
+#else
+#error "WHVI_F16_UNPACK: the shipped library has one form (1)"
 #endif
     }
     static __device__ __forceinline__ u32x4 pack(const acc (&v)[VEC])
     {
-#if defined(WHVI_F16_PACK_EXP) && WHVI_F16_PACK_EXP == 1   /* timing experiment only: bf16's pack (wrong values) */
+#if defined(WHVI_TUNING_BUILD) && defined(WHVI_F16_PACK_EXP) && WHVI_F16_PACK_EXP == 1   /* timing experiment only: bf16's pack (WRONG values) */
         u32x4 rr;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -179,9 +184,6 @@ template <> struct Elem<__hip_bfloat16> {
     static __device__ __forceinline__ u32x4 pack(const acc (&v)[VEC])
     {
         u32x4 r;
-#ifndef WHVI_BF16_PACK
-#define WHVI_BF16_PACK 1
-#endif
 #if WHVI_BF16_PACK == 1
         // one v_cvt_pk_bf16_f32 per output dword (low half <- first operand).  From `rne(lo) | rne(hi) << 16` the compiler
         // makes TWO of them (upper lane unused) plus a v_or_b32_sdwa: 192 instead of 64 instructions per tile.
@@ -228,9 +230,6 @@ __device__ __forceinline__ void tile_store_stream(u32x4 *tile_base, int lane, in
 // can be partial; its missing chunks belong to rows that do not exist (rows never straddle
 // tiles), so they are read as zero and never stored.
 template <typename T, int LOG2D, int K, int POLICY, bool PREFETCH, bool NT, int BLOCK = 256, int ALIGN = 0, bool SIGNED = false>
-#ifndef WHVI_ROWS_WAVES_PER_EU
-#define WHVI_ROWS_WAVES_PER_EU 1      // tuning hook (tools/probe_exp.py builds): minimum waves per SIMD to allocate for
-#endif
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WHVI_ROWS_WAVES_PER_EU)))
 fwht_rows_kernel(u32x4 *dst, const u32x4 *src, int64_t n_chunks, int64_t n_tiles)
 {
@@ -261,9 +260,6 @@ fwht_rows_kernel(u32x4 *dst, const u32x4 *src, int64_t n_chunks, int64_t n_tiles
         if constexpr (POLICY == POLICY_LDS)
             fwht_tile_lds<A, VEC, K, LOG2D>(r, lane, reinterpret_cast<A *>(whvi_smem) + wave * lds_slab_floats<VEC, K>());
         else
-#ifndef WHVI_ROWS_PKMASK
-#define WHVI_ROWS_PKMASK 0
-#endif
         // SIGNED (f32 streams of D = 512 .. 2048, chosen by the dispatch): the signed DPP stages of fwht_tile.hpp plus ONE
         // repair multiply per element at the end, fma(r, sigma, +0): exact for every non-zero value, and an exact
         // cancellation (+0 under either convention) stays +0.  Bit-identical to the unsigned network except that a
@@ -636,9 +632,7 @@ inline FastDiv make_fastdiv(uint32_t d)
 // one scalar per row.  EYE: src is not read; row i of each group is c[i] * e_i (the first group_rows
 // rows of torch.diag(s2), src/weights.py:73).  Every multiply is its own rounding (built with -ffp-contract=off), like
 // the reference's separate matmul_diag_left kernels (src/utils.py:4-12).
-#ifndef WHVI_FUSED_PKMASK
-#define WHVI_FUSED_PKMASK 2     // packed adds in the permlane stages only; the TU is built with -fno-slp-vectorize (Makefile)
-#endif
+// (WHVI_FUSED_PKMASK = 2, tuning.hpp: packed adds in the permlane stages only; the TU is built with -fno-slp-vectorize)
 template <typename T, int LOG2D, int K, int AXIS, bool EYE, bool NT, int BLOCK, int POLICY = POLICY_DPP,
           bool STAGE_AC = false>
 __global__ void __launch_bounds__(BLOCK)
@@ -687,9 +681,6 @@ fused_shs_kernel(u32x4 *dst, const u32x4 *src, const T *a, const T *b, const T *
 
     // The two transforms of the pipeline use the signed DPP form (fwht_tile.hpp): the first leaves the tile with
     // sigma = (-1)^popcount(lane & mask), the scalings between them commute with it, the second takes it back to 0.
-#ifndef WHVI_FUSED_SIGNED
-#define WHVI_FUSED_SIGNED 1
-#endif
     constexpr bool SIGNED = WHVI_FUSED_SIGNED && POLICY == POLICY_DPP;
     constexpr int SIGN_MID = SIGNED ? fwht_sign_out<VEC, LOG2D>(0) : 0;
     static_assert(!SIGNED || fwht_sign_out<VEC, LOG2D>(SIGN_MID) == 0, "two transforms restore the sign convention");

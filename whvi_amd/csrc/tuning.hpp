@@ -1,0 +1,40 @@
+#pragma once
+// whvi_amd/csrc/tuning.hpp -- every switch that exists for MEASUREMENTS only, in one place.
+//
+// The shipped library (whvi_amd/csrc/Makefile never defines WHVI_TUNING_BUILD) contains none of them: no getenv, no
+// alternative instruction forms, no trace hooks -- its launch form depends on its arguments alone
+// (tests/test_abi.py::test_shipped_library_reads_no_environment).  Probe builds (`make -C whvi_amd/csrc tuning
+// [DEFS=-D...]` -> whvi_amd/_exp/libwhvi_hip_tuning.so, loaded by tools/ through WHVI_HIP_LIB) define it and get
+//   * WHVI_TUNE_ENV(name): environment A/B switches of the dispatch (read once per process), DESIGN.md 6.3;
+//   * the -D overrides below, some of which produce WRONG VALUES on purpose (timing-only instruction swaps).
+#ifdef WHVI_TUNING_BUILD
+#include <stdlib.h>
+#define WHVI_TUNE_ENV(name) getenv(name)
+#else
+#define WHVI_TUNE_ENV(name) ((const char *)nullptr)
+#if defined(WHVI_F16_UNPACK) || defined(WHVI_F16_PACK_EXP) || defined(WHVI_BF16_PACK) || defined(WHVI_ROWS_WAVES_PER_EU) || \
+    defined(WHVI_ROWS_PKMASK) || defined(WHVI_FUSED_PKMASK) || defined(WHVI_FUSED_SIGNED) || defined(WHVI_EXP_UNFUSED_DPP) || \
+    defined(WHVI_NO_PK) || defined(WHVI_BLOCK_TRACE)
+#error "kernel tuning switches need -DWHVI_TUNING_BUILD (make -C whvi_amd/csrc tuning DEFS=-D...)"
+#endif
+#endif
+
+// ---- production values (a tuning build may override them with -D) ------------------------------------------------
+#ifndef WHVI_F16_UNPACK
+#define WHVI_F16_UNPACK 1          // fp16 unpack with an explicit shift for the high half (kernels.hpp: Elem<__half>)
+#endif
+#ifndef WHVI_BF16_PACK
+#define WHVI_BF16_PACK 1           // one v_cvt_pk_bf16_f32 per output dword
+#endif
+#ifndef WHVI_ROWS_WAVES_PER_EU
+#define WHVI_ROWS_WAVES_PER_EU 1   // minimum waves per SIMD fwht_rows_kernel is allocated for
+#endif
+#ifndef WHVI_ROWS_PKMASK
+#define WHVI_ROWS_PKMASK 0         // explicit v_pk_add_f32 stages of the plain row kernel: none (fwht_tile.hpp)
+#endif
+#ifndef WHVI_FUSED_PKMASK
+#define WHVI_FUSED_PKMASK 2        // fused kernel: packed adds in the permlane stages only (TU built with -fno-slp-vectorize)
+#endif
+#ifndef WHVI_FUSED_SIGNED
+#define WHVI_FUSED_SIGNED 1        // fused kernel: signed DPP lane stages
+#endif

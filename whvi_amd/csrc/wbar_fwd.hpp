@@ -116,14 +116,14 @@ inline void launch_wbar_fwd(void *dst, const void *s1, const void *u, const void
     const FastDiv dr = make_fastdiv((uint32_t)R), ds = make_fastdiv((uint32_t)S);
     const unsigned grid = (unsigned)((n_tiles + 3) / 4);
     // Cache-resident results: quarter-size tiles (never less than one row), four times the waves with a quarter of the
-    // work each -- same reasoning and threshold as the backward kernel (wbar_bwd.hpp); WHVI_WBAR_FWD_TILES=big|small
-    // overrides (tuning, read once).
+    // work each -- same reasoning and threshold as the backward kernel (wbar_bwd.hpp); tuning builds:
+    // WHVI_WBAR_FWD_TILES=big|small overrides (read once).
     constexpr int LVc = ilog2(VEC);
     constexpr int NEED = (LOG2D > LVc + 6) ? (1 << (LOG2D - LVc - 6)) : 1;
     constexpr int KS = NEED > 4 ? NEED : 4;
     // blocks per matrix / 8 when the XCD-sliced order applies (see the kernel): a mean matrix is added, every matrix
     // is a whole number of 8 x 4-tile groups, and the grid is exactly the matrices' blocks
-    static const bool xcd_off = getenv("WHVI_WBAR_FWD_XCD") != nullptr && getenv("WHVI_WBAR_FWD_XCD")[0] == '0';   // A/B switch
+    static const bool xcd_off = [] { const char *e = WHVI_TUNE_ENV("WHVI_WBAR_FWD_XCD"); return e != nullptr && e[0] == '0'; }();   // A/B switch (tuning builds)
     const uint32_t n_mats = (uint32_t)(R > 0 ? rows / R : 0);
     // (streaming launches only: 1 GiB of D = 2048 matrices 282 -> 194 us, 2 GiB 548 -> 323 = the rate without a mean
     // matrix, D = 4096 x 16 297 -> 254; the cache-resident quarter-tile launches are faster in plain order -- 256 MiB:
@@ -134,11 +134,12 @@ inline void launch_wbar_fwd(void *dst, const void *s1, const void *u, const void
         return (uint32_t)(per_matrix / group);
     };
     if constexpr (KS < K) {
-        static const char *tune = getenv("WHVI_WBAR_FWD_TILES");
+        static const char *tune = WHVI_TUNE_ENV("WHVI_WBAR_FWD_TILES");
         const bool small = tune ? tune[0] == 's' : (n_chunks * 16 <= NT_MIN_BYTES);
-        const bool small_nt = tune && tune[0] == 's' && tune[1] == 'n' && n_chunks * 16 >= NT_MIN_BYTES;     // "sn": experiment
         if (small) {
             const int64_t tiles_s = (n_chunks + 64 * KS - 1) / (64 * KS);
+#ifdef WHVI_TUNING_BUILD
+            const bool small_nt = tune && tune[0] == 's' && tune[1] == 'n' && n_chunks * 16 >= NT_MIN_BYTES;     // "sn": experiment
             if (small_nt) {
                 note_launch<T>("wbar_fwd_kernel", LOG2D, KS, true);
                 hipLaunchKernelGGL((wbar_fwd_kernel<T, LOG2D, KS, true>), dim3((unsigned)((tiles_s + 3) / 4)), dim3(256), 0, st,
@@ -146,6 +147,7 @@ inline void launch_wbar_fwd(void *dst, const void *s1, const void *u, const void
                                    tiles_s, (uint32_t)rows, dr, ds, (uint32_t)u_group, (uint32_t)u_first, xcd_blocks_for(KS, true), n_mats);
                 return;
             }
+#endif
             note_launch<T>("wbar_fwd_kernel", LOG2D, KS, false);
             hipLaunchKernelGGL((wbar_fwd_kernel<T, LOG2D, KS, false>), dim3((unsigned)((tiles_s + 3) / 4)), dim3(256), 0, st,
                                (u32x4 *)dst, (const T *)s1, (const T *)u, (const T *)s2, (const u32x4 *)base, n_chunks,

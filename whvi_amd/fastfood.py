@@ -39,8 +39,11 @@ def _pipeline(x, a, b, c, n_samples, sample_stride):
     """a * fwht(b[s(r)] * fwht(c * x[r])) for every row r, s(r) = (r // sample_stride) % n_samples."""
     if x.device.type == "cuda":
         from whvi_amd import _hip
-        return _hip.fused_shs(x, a, b, c, axis="col", n_samples=n_samples, sample_stride=sample_stride)
-    rows = torch.arange(x.size(0)) // sample_stride % n_samples
+        if _hip.fused_supported(x.dtype, x.size(1)):
+            return _hip.fused_shs(x, a, b, c, axis="col", n_samples=n_samples, sample_stride=sample_stride)
+        # rows longer than one wavefront tile (D > 8192; f64 > 4096): the fused launch does not exist, the plain
+        # transform does (a block per row and beyond) -- the same multiplies and butterflies as separate launches
+    rows = torch.arange(x.size(0), device=x.device) // sample_stride % n_samples
     return a * _fwht(b[rows] * _fwht(c * x))
 
 

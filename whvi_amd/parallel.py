@@ -74,21 +74,61 @@ def sample_seed(base_seed: int, rank: int) -> int:
     return (int(base_seed) * 1_000_003 + 7919 * (rank + 1)) % (2 ** 63 - 1)
 
 
+def _inkernel_rng_modules(net: torch.nn.Module):
+    """(index, module) of every layer that draws eps inside the reparameterisation kernel (``net.set_inkernel_rng()``)."""
+    for index, module in enumerate(net.modules()):
+        if getattr(module, "inkernel_rng", False) and hasattr(type(module), "inkernel_rng"):
+            yield index, module
+
+
 def seed_inkernel_rng(net: torch.nn.Module, base_seed: int, rank: int = None) -> int:
-    """Give every layer that draws eps inside the reparameterisation kernel (``net.set_inkernel_rng()``) a fresh
-    Philox state whose seed depends on (base_seed, RANK, layer index), offset 0.  torch's generators do not reach
-    that stream, so without this all ranks of a job started from one ``torch.manual_seed`` would draw identical eps.
-    Returns the number of layers seeded."""
+    """Re-seed every layer that draws eps inside the reparameterisation kernel (``net.set_inkernel_rng()``): Philox seed
+    from (base_seed, RANK, layer index), offset 0.  torch's generators do not reach that stream, so without this all
+    ranks of a job started from one ``torch.manual_seed`` would draw identical eps.
+
+    The state is re-seeded IN PLACE whenever the layer already has one: a captured hipGraph (``GraphedPredictor``,
+    ``GraphedTrainStep``) has the state tensor's device address baked into its launches, so replacing the tensor would
+    leave the graph reading the seed and writing the offset through memory the caching allocator has since handed to
+    someone else.  Returns the number of layers seeded."""
     from whvi_amd import _hip
     r = _world()[0] if rank is None else rank
     count = 0
-    for index, module in enumerate(net.modules()):
-        if getattr(module, "inkernel_rng", False) and hasattr(type(module), "inkernel_rng"):
-            device = next(module.parameters()).device
-            seed = (sample_seed(base_seed, r) + 104_729 * (index + 1)) % (2 ** 62)
+    for index, module in _inkernel_rng_modules(net):
+        device = next(module.parameters()).device
+        seed = (sample_seed(base_seed, r) + 104_729 * (index + 1)) % (2 ** 62)
+        state = getattr(module, "_rng_state", None)
+        if state is None or state.device != device:
             module._rng_state = _hip.new_rng_state(device, seed=seed)
-            count += 1
+        else:
+            state.copy_(torch.tensor([seed, 0, 0], dtype=torch.int64))
+        count += 1
     return count
+
+
+class _ForkedInkernelRng:
+    """``with _ForkedInkernelRng(net):`` -- what ``torch.random.fork_rng`` does for torch's generators, for the in-kernel
+    Philox states: the values are saved on entry and copied back (into the SAME tensors) on exit, so an evaluation pass
+    that re-seeds them neither disturbs the training stream (which would otherwise restart from the same seed at offset
+    0 after every evaluation and repeat its eps) nor moves a tensor a captured graph points at."""
+
+    def __init__(self, net):
+        self.net = net
+
+    def __enter__(self):
+        self.saved = []
+        for _, module in _inkernel_rng_modules(self.net):
+            state = getattr(module, "_rng_state", None)
+            self.saved.append((module, state, None if state is None else state.clone()))
+        return self
+
+    def __exit__(self, *exc):
+        for module, state, values in self.saved:
+            if state is None:
+                module._rng_state = None       # had none: the training stream still draws its own seed on first use
+            else:
+                state.copy_(values)
+                module._rng_state = state
+        return False
 
 
 def gather_predictions(local: torch.Tensor, counts=None) -> torch.Tensor:
@@ -129,7 +169,7 @@ def mc_sharded_forward(net, x: torch.Tensor, n_samples: int, base_seed: int = 0)
     counts = [shard_bounds(n_samples, r, world)[1] - shard_bounds(n_samples, r, world)[0] for r in range(world)]
     devices = [x.device] if x.device.type == "cuda" else []
     n_local = end - begin
-    with torch.random.fork_rng(devices=devices):
+    with torch.random.fork_rng(devices=devices), _ForkedInkernelRng(net):
         torch.manual_seed(sample_seed(base_seed, rank))
         seed_inkernel_rng(net, base_seed, rank)      # the opt-in Philox stream: per rank too, same determinism
         if n_local == 0:

@@ -191,7 +191,13 @@ def _posterior_kl(g_mu, g_rho, lambda_):
     """``sum_j kl_diag_normal(g_mu[j], softplus(g_rho[j]), 0, lambda)`` for ``(J, D)`` parameters -- the ``kl``
     property of every weight flavour (src/weights.py:52-64, :169).  float32 on the GPU: ONE launch of the
     reparameterisation + KL kernel with zero samples (differentiable through its closed-form backward) instead of the
-    formula's ten tiny launches; otherwise the reference's formula (src/utils.py:49-71) as torch ops."""
+    formula's ten tiny launches; otherwise the reference's formula (src/utils.py:49-71) as torch ops.
+
+    Tolerance contract of the GPU float32 value: the same D terms as the reference's formula, added per term and then
+    over 256-element blocks instead of as five separate D-term sums -- so it agrees with ``kl_diag_normal`` to float32
+    summation noise (<= 1e-5 relative; pinned at 2e-6 by tests/test_fused_gpu.py::test_kl_property_tolerance_contract),
+    not bit for bit; ``lambda_ <= 0`` raises where the formula would return NaN.  float64 parameters and host tensors
+    evaluate the formula itself."""
     if g_mu.device.type == "cuda" and g_mu.dtype == torch.float32:
         eps = g_mu.new_empty((g_mu.shape[0], 0, g_mu.shape[1]))
         kl = ReparamKLFunction.apply(g_mu, g_rho, eps, lambda_)[1]
