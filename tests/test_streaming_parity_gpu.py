@@ -26,15 +26,14 @@ def _bits(a):
     return a.view({4: np.uint32, 8: np.uint64}[a.dtype.itemsize])
 
 
-def expected_fused_kernel(dtype, log2d, per_sample, sample_major=False):
+def expected_fused_kernel(dtype, log2d, per_sample, layout):
     """The symbol production dispatches for a column-axis launch of >= 32 tiles per CU beyond the Infinity Cache
-    (dispatch.hpp: launch_fused)."""
-    name = "float" if dtype == torch.float32 else "double"
-    if dtype == torch.float64 and log2d == 12:
-        # one 32 KiB row per wave (128 data registers): 256-thread blocks, cached accesses, vectors requested ahead
-        return "whvi::fused_shs_kernel<double, 12, 32, 1, false, false, 256, 0, false>"
-    staged = "false" if per_sample else "true"             # shared a / c are staged in LDS
-    return f"whvi::fused_shs_kernel<{name}, {log2d}, 16, 1, false, true, 256, 0, {staged}>"
+    (dispatch.hpp: launch_fused).  Last template argument = which scale vectors the block stages in LDS (kernels.hpp):
+    1 = a and c (shared ones, or those of the block's one sample), 0 = none (every vector from L2)."""
+    name, esize = ("float", 4) if dtype == torch.float32 else ("double", 8)
+    K = 32 if (dtype == torch.float64 and log2d == 12) else 16      # one f64 row of 4096 per wave: 128 data registers
+    stage = 1 if (layout == "sample" or not per_sample) else 0      # "sample": whole blocks inside one sample
+    return f"whvi::fused_shs_kernel<{name}, {log2d}, {K}, 1, false, true, 256, 0, {stage}>"
 
 
 CASES = [(torch.float32, 9), (torch.float32, 10), (torch.float32, 11), (torch.float32, 12),
@@ -42,27 +41,32 @@ CASES = [(torch.float32, 9), (torch.float32, 10), (torch.float32, 11), (torch.fl
 
 
 @pytest.mark.parametrize("in_place", [True, False])
-@pytest.mark.parametrize("sample_major", [False, True])
+@pytest.mark.parametrize("layout", ["batch", "sample", "sample_ragged"])
 @pytest.mark.parametrize("per_sample", [False, True])
 @pytest.mark.parametrize("dtype,log2d", CASES)
-def test_fused_streaming_instantiation_vs_oracle(dtype, log2d, per_sample, sample_major, in_place, hip_lib):
+def test_fused_streaming_instantiation_vs_oracle(dtype, log2d, per_sample, layout, in_place, hip_lib):
+    """layout: "batch" = rows in (batch, sample, D) order (sample_stride = 1, BASELINE config 3's order); "sample" =
+    (sample, batch, D) with the batch a multiple of the rows per block (fastfood's order: every block inside one sample);
+    "sample_ragged" = the same with an odd batch (blocks straddle samples: no per-block staging of per-sample vectors)."""
     d = 1 << log2d
     esize = 4 if dtype == torch.float32 else 8
     S = 48                                               # not a power of two: the FastDiv row -> sample map
     B = (320 * MIB) // (d * esize * S) + 1               # >= 320 MiB; B * S rows
+    B = (B + 31) // 32 * 32 + (1 if layout == "sample_ragged" else 0)      # 32 = the most rows a block holds (D = 512 f32)
     rows = B * S
     assert rows * d * esize >= 320 * MIB
     npdt = np.float32 if dtype == torch.float32 else np.float64
-    g = torch.Generator(device=DEV).manual_seed(1000 * log2d + 10 * esize + 2 * per_sample + sample_major)
+    g = torch.Generator(device=DEV).manual_seed(1000 * log2d + 10 * esize + 2 * per_sample + len(layout))
     x = torch.randn(rows, d, device=DEV, dtype=dtype, generator=g)
     nv = S if per_sample else 1
     a = torch.randn(nv, d, device=DEV, dtype=dtype, generator=g) * 0.1
     c = torch.randn(nv, d, device=DEV, dtype=dtype, generator=g) * 0.1
     b = torch.randn(S, d, device=DEV, dtype=dtype, generator=g)
-    stride = B if sample_major else 1
+    stride = 1 if layout == "batch" else B
     rng = np.random.default_rng(7 + log2d)
     rpt = max(1, (16384 // esize) // d)                  # rows per 16 KiB tile
-    edge = [0, 1, rpt - 1, rpt, 4 * rpt - 1, 4 * rpt, S - 1, S, B - 1, B, B + 1, rows // 2, rows - rpt - 1, rows - 2, rows - 1]
+    edge = [0, 1, rpt - 1, rpt, 4 * rpt - 1, 4 * rpt, S - 1, S, B - 1, B, B + 1, 2 * B - 1, 2 * B, rows // 2,
+            rows - B - 1, rows - B, rows - rpt - 1, rows - 2, rows - 1]
     idx = np.unique(np.clip(np.concatenate([edge, rng.integers(0, rows, 72)]), 0, rows - 1))
     assert len(idx) >= 64
     tidx = torch.from_numpy(idx).to(DEV)
@@ -70,7 +74,7 @@ def test_fused_streaming_instantiation_vs_oracle(dtype, log2d, per_sample, sampl
     out = _hip.fused_shs(x, a if per_sample else a[0], b, c if per_sample else c[0], axis="col", n_samples=S,
                          sample_stride=stride, out=x if in_place else None, a_per_sample=per_sample,
                          c_per_sample=per_sample)
-    assert _hip.last_kernel() == expected_fused_kernel(dtype, log2d, per_sample, sample_major), _hip.last_kernel()
+    assert _hip.last_kernel() == expected_fused_kernel(dtype, log2d, per_sample, layout), _hip.last_kernel()
     assert (out.data_ptr() == x.data_ptr()) == in_place
     got = out[tidx].cpu().numpy()
     # oracle on the gathered rows: every gathered row is its own "sample" carrying its row's b (and a, c when per-sample)

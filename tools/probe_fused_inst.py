@@ -25,19 +25,22 @@ def timed(fn, iters=20, warm=25):
 
 
 print("library:", _hip.LIB_PATH)
+LAYOUTS = sys.argv[1].split(",") if len(sys.argv) > 1 else ["batch-major"]      # batch-major: (batch, sample, D); sample-major
 for dtype in (torch.float32, torch.float64):
+  for layout in LAYOUTS:
     for d in (512, 2048, 4096):
         S = 64
         rows = (1 << 32) // (d * (4 if dtype == torch.float32 else 8))
+        stride = 1 if layout == "batch-major" else rows // S
         x = torch.randn(rows, d, device=dev, dtype=dtype)
         sgn = lambda n: ((torch.randint(0, 2, (n, d), device=dev) * 2 - 1).to(dtype) * d ** -0.5)   # noqa: E731
         g = torch.randn(S, d, device=dev, dtype=dtype)
         for per_sample in (False, True):
             a, c = (sgn(S), sgn(S)) if per_sample else (sgn(1)[0], sgn(1)[0])
-            ms = timed(lambda: _hip.fused_shs(x, a, g, c, axis="col", n_samples=S, sample_stride=1, out=x,
+            ms = timed(lambda: _hip.fused_shs(x, a, g, c, axis="col", n_samples=S, sample_stride=stride, out=x,
                                               a_per_sample=per_sample, c_per_sample=per_sample))
             gbs = 2 * x.numel() * x.element_size() / ms / 1e6
-            print(f"{str(dtype)[6:]:8s} D={d:5d} per-sample a/c={int(per_sample)}: {ms:.4f} ms {gbs:7.1f} GB/s = {gbs / 8000:.3f} "
+            print(f"{str(dtype)[6:]:8s} {layout:12s} D={d:5d} per-sample a/c={int(per_sample)}: {ms:.4f} ms {gbs:7.1f} GB/s = {gbs / 8000:.3f} "
                   f"finite={bool(torch.isfinite(x[::4099]).all())}  {_hip.last_kernel()}", flush=True)
         del x
 # stacked layer of BASELINE config 4: WHVILinear(3, 1024) = 256 sub-matrices of D = 4, 16 MC samples (+ mean)

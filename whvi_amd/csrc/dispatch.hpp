@@ -422,27 +422,41 @@ inline void launch_fused(void *dst, const void *src, const void *a, const void *
     const int64_t n_tiles = (n_chunks + 64 * K - 1) / (64 * K);
     const FastDiv ds = make_fastdiv((uint32_t)sample_stride), dn = make_fastdiv((uint32_t)n_samples),
                   dg = make_fastdiv((uint32_t)group_rows);
-    const bool big = SMALL_TILE && n_tiles >= (int64_t)32 * num_cu();
+    // "big": enough tiles to fill the chip several times over (32 per CU; 16 for the 32 KiB tiles of one f64 row of 4096)
+    const bool big = n_tiles >= (int64_t)(SMALL_TILE ? 32 : 16) * num_cu();
     const bool nt = big && stream_sized(n_chunks * 16, dst, src);
 #define WHVI_FUSED(AX, EYE, NT, BLK, POL, STG)                                                          \
     do {                                                                                                \
-        note_launch<T>("fused_shs_kernel", LOG2D, K, (int)AX, (bool)EYE, (bool)NT, (int)BLK, (int)POL, (bool)STG); \
+        note_launch<T>("fused_shs_kernel", LOG2D, K, (int)AX, (bool)EYE, (bool)NT, (int)BLK, (int)POL, (int)STG); \
+        constexpr size_t smem = ((POL == POLICY_LDS) ? (size_t)(BLK / 64) * slab_bytes : 0) +           \
+                                (((STG) == STAGE_ABC ? 3 : ((STG) == STAGE_AC ? 2 : 0)) * sizeof(typename Elem<T>::acc) << LOG2D); \
+        if constexpr (smem > 64 * 1024)   /* per launch: the attribute belongs to the CURRENT device's copy */ \
+            (void)hipFuncSetAttribute((const void *)fused_shs_kernel<T, LOG2D, K, AX, EYE, NT, BLK, POL, STG>, \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);           \
         hipLaunchKernelGGL((fused_shs_kernel<T, LOG2D, K, AX, EYE, NT, BLK, POL, STG>),                 \
-                           dim3((unsigned)((n_tiles + (BLK / 64) - 1) / (BLK / 64))), dim3(BLK),        \
-                           ((POL == POLICY_LDS) ? (size_t)(BLK / 64) * slab_bytes : 0) +                \
-                               ((STG) ? (2 * sizeof(typename Elem<T>::acc)) << LOG2D : 0), st,          \
+                           dim3((unsigned)((n_tiles + (BLK / 64) - 1) / (BLK / 64))), dim3(BLK), smem, st, \
                            (u32x4 *)dst, (const u32x4 *)src, (const T *)a, (const T *)b, (const T *)c,  \
                            n_chunks, n_tiles, ds, dn, dg, flags);                                       \
     } while (0)
     constexpr bool LDS_OK = sizeof(typename Elem<T>::acc) == 4 && K * VEC == 64;
     constexpr size_t slab_bytes = (size_t)K * (64 * VEC + VEC) * 4;   // lds_slab_floats<VEC, K>() * 4
-    // Column-axis launch of big problems, measured on MI355X (tools/tune_fused.py, D = 2048 / 4096,
+    (void)LDS_OK;
+    // Column-axis launch of big problems, measured on MI355X (round 1, tools/tune_fused.py, D = 2048 / 4096,
     // 4 GiB): 256-thread blocks beat 512 (12 vs 8 waves per CU at ~200 VGPRs), staging the shared a / c
     // vectors in LDS is worth +5 %, non-temporal data accesses +4 %, and the LDS-staged butterfly
     // network ties the DPP one (the kernel is bound by its 4x load-instruction stream, not by VALU):
     //   dpp/256/nt/staged 5.05 TB/s | lds/256 5.00 | dpp/256 4.70 | dpp/512/nt 4.04 | lds/512/nt 4.40
     //   (one 8 KiB row per wave at D = 2048 -- 106 VGPRs, twice the waves -- ties at 4.87; 1024-thread blocks 4.4)
-    // Tuning builds only: WHVI_FUSED_TUNE=<policy 0|2><block 2|5 (unused: always 256)><nt 0|1><stage 0|1> overrides (read once).
+    // Round 3 -- which vectors a block stages in LDS (kernels.hpp: STAGE_*):
+    //   * rows in (sample, batch, D) order with sample_stride a multiple of the rows per block: every block lies inside
+    //     ONE sample, so that sample's a and c are staged (STAGE_AC) also when they are per-sample: 6.35-6.40 TB/s for f32
+    //     at D = 512 .. 4096 against 5.4-5.7 with the three vectors from L2;
+    //   * otherwise shared a / c are staged and per-sample ones come from L2 (STAGE_NONE).
+    //   Staging b as well (STAGE_ABC, tuning builds) ties at D = 4096 f32 / D = 2048 f64 (6.41 vs 6.38, 6.38 vs 6.34) and
+    //   LOSES at D <= 2048 f32 (5.76 vs 6.39) and for f64 rows of 4096 (96 KiB of LDS: one block per CU, 4.1 vs 5.8).
+    // Tuning builds only: WHVI_FUSED_TUNE=<policy 0|2><block 2|5 (unused: always 256)><nt 0|1><stage 0|1|3> overrides (read once).
+    constexpr int64_t rows_per_block = ((int64_t)4 * 64 * K * VEC) >> LOG2D;       // >= 1 for every staged shape (LOG2D <= 12)
+    const bool one_sample_blocks = rows_per_block >= 1 && sample_stride % rows_per_block == 0;
 #ifdef WHVI_TUNING_BUILD
     static const char *tune_env = [] {          // ignored unless it is exactly four digits: never read past the NUL
         const char *e = WHVI_TUNE_ENV("WHVI_FUSED_TUNE");
@@ -451,58 +465,60 @@ inline void launch_fused(void *dst, const void *src, const void *a, const void *
             if (e[i] < '0' || e[i] > '9') return (const char *)nullptr;
         return e;
     }();
-    const int t_pol = tune_env ? tune_env[0] - '0' : 0;
-    const int t_nt = tune_env ? tune_env[2] - '0' : (nt ? 1 : 0);
-    const int t_stg = tune_env ? tune_env[3] - '0' : 1;
-    (void)t_pol; (void)t_nt; (void)t_stg;
+#else
+    constexpr const char *tune_env = nullptr;
 #endif
+    int stage = STAGE_NONE;
+    if (big) {
+        if (one_sample_blocks || flags == 0) stage = STAGE_AC;
+    }
+    bool use_nt = nt;
+    if (tune_env != nullptr) {
+        use_nt = tune_env[2] != '0';
+        const int want = tune_env[3] - '0';
+        if (want == STAGE_NONE || (want == STAGE_AC && (flags == 0 || one_sample_blocks)) || (want == STAGE_ABC && one_sample_blocks))
+            stage = want;
+    }
 #ifdef WHVI_TUNING_BUILD
-#define WHVI_FUSED_F32_SHARED(AX, EYE)                                                                  \
-    do {                                                                                                \
-        const int key = (t_pol == 2 ? 4 : 0) | (t_nt ? 2 : 0) | (t_stg ? 1 : 0);                        \
-        switch (key) {                                                                                  \
-        case 0: WHVI_FUSED(AX, EYE, false, 256, POLICY_DPP, false); break;                              \
-        case 1: WHVI_FUSED(AX, EYE, false, 256, POLICY_DPP, true); break;                               \
-        case 2: WHVI_FUSED(AX, EYE, true, 256, POLICY_DPP, false); break;                               \
-        case 3: WHVI_FUSED(AX, EYE, true, 256, POLICY_DPP, true); break;                                \
-        case 4: WHVI_FUSED(AX, EYE, false, 256, POLICY_LDS, false); break;                              \
-        case 5: WHVI_FUSED(AX, EYE, false, 256, POLICY_LDS, true); break;                               \
-        case 6: WHVI_FUSED(AX, EYE, true, 256, POLICY_LDS, false); break;                               \
-        default: WHVI_FUSED(AX, EYE, true, 256, POLICY_LDS, true); break;                               \
-        }                                                                                               \
-    } while (0)
-#else      /* production: DPP network, shared a / c staged in LDS */
-#define WHVI_FUSED_F32_SHARED(AX, EYE)                                                                  \
-    do {                                                                                                \
-        if (nt) WHVI_FUSED(AX, EYE, true, 256, POLICY_DPP, true);                                       \
-        else WHVI_FUSED(AX, EYE, false, 256, POLICY_DPP, true);                                         \
-    } while (0)
+#define WHVI_FUSED_ABC(AX, EYE, POL)                                                                    \
+    if (stage == STAGE_ABC) { if (use_nt) WHVI_FUSED(AX, EYE, true, 256, POL, STAGE_ABC); else WHVI_FUSED(AX, EYE, false, 256, POL, STAGE_ABC); break; }
+#else
+#define WHVI_FUSED_ABC(AX, EYE, POL)
 #endif
+#define WHVI_FUSED_STAGED(AX, EYE, POL)                                                                 \
+    do {                                                                                                \
+        WHVI_FUSED_ABC(AX, EYE, POL);                                                                   \
+        if (stage == STAGE_AC) { if (use_nt) WHVI_FUSED(AX, EYE, true, 256, POL, STAGE_AC); else WHVI_FUSED(AX, EYE, false, 256, POL, STAGE_AC); } \
+        else if (use_nt) WHVI_FUSED(AX, EYE, true, 256, POL, STAGE_NONE);                               \
+        else WHVI_FUSED(AX, EYE, false, 256, POL, STAGE_NONE);                                          \
+    } while (0)
 #define WHVI_FUSED_GEOM(AX, EYE)                                                                        \
     do {                                                                                                \
-        if constexpr (SMALL_TILE && AX == WHVI_AXIS_COL && !(EYE) && sizeof(T) == 8 &&                  \
-                      LOG2D >= 9 && LOG2D <= 12) {                                                      \
-            if (big && flags == 0) {     /* f64: shared a / c staged in LDS too (2 x 8 x D bytes) */    \
-                if (nt) WHVI_FUSED(AX, EYE, true, 256, POLICY_DPP, true);                               \
-                else WHVI_FUSED(AX, EYE, false, 256, POLICY_DPP, true);                                 \
+        if constexpr (AX == WHVI_AXIS_COL && !(EYE) && sizeof(T) >= 4 && LOG2D >= 9 && LOG2D <= 12) {   \
+            if (big) {                                                                                  \
+                WHVI_FUSED_TUNED_POLICY(AX, EYE);                                                       \
+                WHVI_FUSED_STAGED(AX, EYE, POLICY_DPP);                                                 \
                 break;                                                                                  \
             }                                                                                           \
         }                                                                                               \
-        if constexpr (SMALL_TILE && AX == WHVI_AXIS_COL && !(EYE) && LDS_OK && sizeof(T) == 4 &&        \
-                      LOG2D >= 9 && LOG2D <= 12) {                                                      \
-            if (big && flags == 0) {                                                                    \
-                WHVI_FUSED_F32_SHARED(AX, EYE);                                                         \
-                break;                                                                                  \
-            }                                                                                           \
-        }                                                                                               \
-        if (nt) WHVI_FUSED(AX, EYE, true, 256, POLICY_DPP, false);                                      \
-        else WHVI_FUSED(AX, EYE, false, 256, POLICY_DPP, false);                                        \
+        if (nt) WHVI_FUSED(AX, EYE, true, 256, POLICY_DPP, STAGE_NONE);                                 \
+        else WHVI_FUSED(AX, EYE, false, 256, POLICY_DPP, STAGE_NONE);                                   \
     } while (0)
+#ifdef WHVI_TUNING_BUILD     /* the LDS-staged butterfly network as an A/B (f32, 64-register tiles) */
+#define WHVI_FUSED_TUNED_POLICY(AX, EYE)                                                                \
+    if constexpr (LDS_OK) {                                                                             \
+        if (tune_env != nullptr && tune_env[0] == '2') { WHVI_FUSED_STAGED(AX, EYE, POLICY_LDS); break; } \
+    }
+#else
+#define WHVI_FUSED_TUNED_POLICY(AX, EYE)
+#endif
     if (src == nullptr) WHVI_FUSED_GEOM(WHVI_AXIS_ROW, true);
     else if (axis == WHVI_AXIS_ROW) WHVI_FUSED_GEOM(WHVI_AXIS_ROW, false);
     else WHVI_FUSED_GEOM(WHVI_AXIS_COL, false);
 #undef WHVI_FUSED_GEOM
-#undef WHVI_FUSED_F32_SHARED
+#undef WHVI_FUSED_TUNED_POLICY
+#undef WHVI_FUSED_STAGED
+#undef WHVI_FUSED_ABC
 #undef WHVI_FUSED
 }
 

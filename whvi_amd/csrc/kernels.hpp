@@ -633,8 +633,35 @@ inline FastDiv make_fastdiv(uint32_t d)
 // rows of torch.diag(s2), src/weights.py:73).  Every multiply is its own rounding (built with -ffp-contract=off), like
 // the reference's separate matmul_diag_left kernels (src/utils.py:4-12).
 // (WHVI_FUSED_PKMASK = 2, tuning.hpp: packed adds in the permlane stages only; the TU is built with -fno-slp-vectorize)
+//
+// STAGE (AXIS_COL): which scale vectors the BLOCK copies into LDS once, to be multiplied straight out of LDS by its waves:
+//   STAGE_NONE  every vector is fetched from L2 by the wave that needs it (small launches; per-sample a / c when the rows
+//               of a block belong to different samples);
+//   STAGE_AC    a and c.  Shared a / c: always possible.  Per-sample a / c: only when all rows of a block belong to ONE
+//               sample (rows in (sample, batch, D) order with sample_stride a multiple of the rows per block -- the host
+//               checks), the block then stages that sample's vectors;
+//   STAGE_ABC   a, b and c of the block's one sample (same condition): no scale vector comes through L2 -> L1 at all.
+constexpr int STAGE_NONE = 0, STAGE_AC = 1, STAGE_ABC = 3;
+
+// 16-byte load at (wave-uniform base pointer) + lane * 16 + byte offset: a raw buffer load with the base in SGPRs -- no
+// 64-bit VGPR address arithmetic per chunk and no address registers (the global_load form of a per-chunk pointer costs a
+// v_add_co / v_addc pair and two VGPRs each).  `bytes` bounds the access (reads beyond it return zeros).
+template <bool NT = false>
+__device__ __forceinline__ u32x4 uniform_ld16(const void *base, uint32_t bytes, int lane, int byte_offset)
+{
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, byte_offset, NT ? (1 << 1) : WHVI_VEC_AUX));
+}
+// the store counterpart; writes beyond `bytes` are dropped.  NT: write-through + non-temporal (see tile_store_stream)
+template <bool NT>
+__device__ __forceinline__ void uniform_st16(void *base, uint32_t bytes, int lane, int byte_offset, const u32x4 &v)
+{
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)bytes, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, lane * 16, byte_offset, NT ? ((1 << 4) | (1 << 1)) : 0);
+}
+
 template <typename T, int LOG2D, int K, int AXIS, bool EYE, bool NT, int BLOCK, int POLICY = POLICY_DPP,
-          bool STAGE_AC = false>
+          int STAGE = STAGE_NONE>
 __global__ void __launch_bounds__(BLOCK)
 fused_shs_kernel(u32x4 *dst, const u32x4 *src, const T *a, const T *b, const T *c,
                  int64_t n_chunks, int64_t n_tiles, FastDiv by_sample_stride, FastDiv by_n_samples,
@@ -650,6 +677,7 @@ fused_shs_kernel(u32x4 *dst, const u32x4 *src, const T *a, const T *b, const T *
     constexpr int SH = LOG2D - LV;           // log2(chunks per row)
     constexpr uint32_t CPR = 1u << SH;
     static_assert(LOG2D >= LV, "fused kernel handles rows of at least one chunk");
+    static_assert(STAGE == STAGE_NONE || (AXIS == WHVI_AXIS_COL && !EYE && sizeof(A) == sizeof(T)), "staging: f32 / f64 column scales");
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -657,24 +685,71 @@ fused_shs_kernel(u32x4 *dst, const u32x4 *src, const T *a, const T *b, const T *
     int64_t blk = blockIdx.x;
     if (NT && (gridDim.x & 7) == 0) blk = (blk & 7) * (int64_t)(gridDim.x >> 3) + (blk >> 3);
     const int64_t t = blk * (BLOCK / 64) + wave;
+    const bool active = t < n_tiles;                          // wave-uniform; a block always has at least one active wave
+    const int64_t base = t * TILE;
+    const uint32_t row0 = (uint32_t)(base >> SH);             // first row of the tile (wave-uniform)
 
+    auto group_index = [&](uint32_t row) __attribute__((always_inline)) -> uint32_t { return by_group_rows.mod(row); };
+    auto sample_index = [&](uint32_t row) __attribute__((always_inline)) -> uint32_t {
+        return by_n_samples.mod(by_sample_stride.div(row));
+    };
+
+    // ---- request order: the block's scale vectors FIRST (L2 hits, back within a microsecond; loads of one wave return in
+    // order, so behind the tile they would only arrive with it), the tile right behind them; the vectors are then written
+    // to LDS and the block barrier passes while the tile's loads are still in flight.  (Round 2 staged, synchronised and
+    // only then asked for the tile: one exposed L2 round trip + barrier per block, which at two waves per SIMD -- f64
+    // rows of 4096 -- nothing hides: 4.8 -> 5.5 TB/s.)
     extern __shared__ __attribute__((aligned(16))) char whvi_smem[];
-    // STAGE_AC (AXIS_COL, shared a and c): the block copies the two D-element vectors into LDS once;
-    // every wave then reads its scale chunks from there instead of issuing 2 x K more global loads
-    // through the L1 / texture path (the kernel's data stream already keeps that path busy).
-    constexpr int STAGED = STAGE_AC ? 2 * (1 << LOG2D) : 0;          // elements of LDS in front of the slabs
+    constexpr int NSTAGED = STAGE == STAGE_ABC ? 3 : (STAGE == STAGE_AC ? 2 : 0);
+    constexpr int STAGED = NSTAGED * (1 << LOG2D);                    // elements of LDS in front of the slabs
     A *const lds_a = reinterpret_cast<A *>(whvi_smem);
     A *const lds_c = lds_a + (1 << LOG2D);
+    A *const lds_b = lds_c + (1 << LOG2D);
     typedef A chunk_t __attribute__((ext_vector_type(VEC)));          // one 16-byte chunk of arithmetic values
-    if constexpr (STAGE_AC) {
-        static_assert(AXIS == WHVI_AXIS_COL && !EYE && sizeof(A) == sizeof(T), "staging: f32 / f64 column scales");
-        for (int i = threadIdx.x * VEC; i < (1 << LOG2D); i += BLOCK * VEC) {
-            if (a != nullptr) *reinterpret_cast<chunk_t *>(lds_a + i) = *reinterpret_cast<const chunk_t *>(a + i);
-            if (c != nullptr) *reinterpret_cast<chunk_t *>(lds_c + i) = *reinterpret_cast<const chunk_t *>(c + i);
-        }
+    constexpr int STG_ITERS = ((1 << LOG2D) + BLOCK * VEC - 1) / (BLOCK * VEC);      // chunks per thread and vector
+    chunk_t stg[NSTAGED > 0 ? NSTAGED : 1][STG_ITERS];
+    const T *stg_src[3] = {nullptr, nullptr, nullptr};                // c, a, b (the order they are needed in)
+    A *const stg_dst[3] = {lds_c, lds_a, lds_b};
+    if constexpr (STAGE != STAGE_NONE) {
+        // the block's sample: read only where a vector is per-sample (all rows of the block then share it: host-checked)
+        const uint32_t blk_row0 = (uint32_t)((blk * (BLOCK / 64) * TILE) >> SH);
+        const size_t s_off = (size_t)sample_index(blk_row0) << LOG2D;
+        stg_src[0] = c == nullptr ? nullptr : c + (c_per_sample ? s_off : 0);
+        stg_src[1] = a == nullptr ? nullptr : a + (a_per_sample ? s_off : 0);
+        stg_src[2] = (STAGE == STAGE_ABC && b != nullptr) ? b + s_off : nullptr;
+#pragma unroll
+        for (int v = 0; v < NSTAGED; ++v)
+            if (stg_src[v] != nullptr) {
+#pragma unroll
+                for (int j = 0; j < STG_ITERS; ++j) {
+                    const int i = (threadIdx.x + j * BLOCK) * VEC;
+                    if (i < (1 << LOG2D)) stg[v][j] = *reinterpret_cast<const chunk_t *>(stg_src[v] + i);
+                }
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // the tile: bounds-checked buffer accesses from its (wave-uniform) base -- chunks of a partial last tile beyond the
+    // buffer read as zero and are never written, waves past the last tile touch nothing: no branch, no per-chunk address
+    const uint32_t tile_bytes = active ? (uint32_t)((n_chunks - base < TILE ? n_chunks - base : (int64_t)TILE) * 16) : 0u;
+    u32x4 raw[EYE ? 1 : K];
+    if constexpr (!EYE) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) raw[k] = uniform_ld16<NT>(src + base, tile_bytes, lane, k * 1024);
+    }
+    if constexpr (STAGE != STAGE_NONE) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int v = 0; v < NSTAGED; ++v)
+            if (stg_src[v] != nullptr) {
+#pragma unroll
+                for (int j = 0; j < STG_ITERS; ++j) {
+                    const int i = (threadIdx.x + j * BLOCK) * VEC;
+                    if (i < (1 << LOG2D)) *reinterpret_cast<chunk_t *>(stg_dst[v] + i) = stg[v][j];
+                }
+            }
         __syncthreads();
     }
-    if (t >= n_tiles) {
+    if (!active) {
         if constexpr (NT) __syncthreads();      // the store-alignment barrier below
         return;
     }
@@ -692,25 +767,37 @@ fused_shs_kernel(u32x4 *dst, const u32x4 *src, const T *a, const T *b, const T *
             fwht_tile<A, VEC, K, LOG2D, POLICY_DPP, WHVI_FUSED_PKMASK, SIGNED, decltype(second)::value ? SIGN_MID : 0>(r, lane);
     };
 
-    const int64_t base = t * TILE;
-    const bool full = base + TILE <= n_chunks;
-    const uint32_t row0 = (uint32_t)(base >> SH);             // first row of the tile (wave-uniform)
-    auto chunk_ok = [&](int k) { return full || (base + k * 64 + lane < n_chunks); };
     // rows never straddle tiles and TILE is a multiple of CPR or vice versa
-    auto chunk_row = [&](int k) -> uint32_t {
+    auto chunk_row = [&](int k) __attribute__((always_inline)) -> uint32_t {
         if constexpr (SH >= 6) return row0 + (uint32_t)((k * 64) >> SH);                 // wave-uniform
         else return row0 + (uint32_t)((k * 64 + lane) >> SH);
     };
-    auto chunk_col = [&](int k) -> uint32_t { return (uint32_t)(k * 64 + lane) & (CPR - 1); };
-    auto group_index = [&](uint32_t row) -> uint32_t { return by_group_rows.mod(row); };
-    auto sample_index = [&](uint32_t row) -> uint32_t {
-        return by_n_samples.mod(by_sample_stride.div(row));
+    auto chunk_col = [&](int k) __attribute__((always_inline)) -> uint32_t { return (uint32_t)(k * 64 + lane) & (CPR - 1); };
+    // scale factors of chunk k: VEC column values (AXIS_COL) or one row scalar broadcast.  Rows of >= 64 chunks (UNIFORM):
+    // the row's sample -- hence its vector's base -- is wave-uniform, computed ONCE per row of the tile (branch-free: a
+    // per-chunk branch on per_sample would cut the phases below into basic blocks the scheduling fences cannot order);
+    // chunk k of the lane then sits at a compile-time offset from that base plus lane * 16.
+    constexpr bool UNIFORM = AXIS == WHVI_AXIS_COL && SH >= 6;
+    constexpr int TILE_ROWS = UNIFORM ? ((K * 64) >> SH) : 1;         // rows of the tile (1, 2, 4, ...)
+    constexpr int CHUNKS_PER_ROW_HERE = UNIFORM ? (int)CPR / 64 : 1;   // k-steps per row
+    struct RowBases { const T *p[TILE_ROWS]; };
+    auto row_bases = [&](const T *vec, bool per_sample) __attribute__((always_inline)) {
+        RowBases rb;
+        const uint32_t keep = per_sample ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+        for (int j = 0; j < TILE_ROWS; ++j)
+            rb.p[j] = vec + ((size_t)(sample_index(row0 + (uint32_t)j) & keep) << LOG2D);
+        return rb;
     };
-    // scale factors of chunk k: VEC column values (AXIS_COL) or one row scalar broadcast
-    auto scale = [&](const T *vec, uint32_t vec_base, int k, A (&out)[VEC]) {
-        if constexpr (AXIS == WHVI_AXIS_COL) {
+    auto scale = [&](const T *vec, bool per_sample, const RowBases &rb, int k, A (&out)[VEC]) {
+        if constexpr (UNIFORM) {
+            E::unpack(uniform_ld16(rb.p[k / CHUNKS_PER_ROW_HERE], (uint32_t)sizeof(T) << LOG2D, lane,
+                                   (k % CHUNKS_PER_ROW_HERE) * 1024), out);
+        } else if constexpr (AXIS == WHVI_AXIS_COL) {
+            const uint32_t vec_base = per_sample ? sample_index(chunk_row(k)) << LOG2D : 0u;
             E::unpack(*reinterpret_cast<const u32x4 *>(vec + (size_t)vec_base + chunk_col(k) * VEC), out);
         } else {
+            const uint32_t vec_base = per_sample ? sample_index(chunk_row(k)) * by_group_rows.d : 0u;
             const A v = (A)vec[(size_t)vec_base + group_index(chunk_row(k))];
 #pragma unroll
             for (int e = 0; e < VEC; ++e) out[e] = v;
@@ -719,36 +806,78 @@ fused_shs_kernel(u32x4 *dst, const u32x4 *src, const T *a, const T *b, const T *
 
     A r[K][VEC];
 
-    // shared a / c staged in LDS: multiply straight out of LDS, chunk by chunk -- no 64-register copy of a
+    // vectors staged in LDS: multiply straight out of LDS, chunk by chunk -- no 64-register copy of a
     // vector is ever live across a transform
-    auto apply_staged = [&](const A *staged) {
+    auto apply_staged = [&](const A *staged) __attribute__((always_inline)) {
+        // eight 16-byte LDS reads in flight, then their eight multiplies (left alone the compiler reads two chunks at a
+        // time and waits for each pair: the LDS latency eight times per vector)
+        constexpr int G = K < 8 ? K : 8;
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const chunk_t v = *reinterpret_cast<const chunk_t *>(staged + chunk_col(k) * VEC);
+        for (int k0 = 0; k0 < K; k0 += G) {
+            chunk_t v[G];
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) r[k][e] = v[e] * r[k][e];
+            for (int g = 0; g < G; ++g) v[g] = *reinterpret_cast<const chunk_t *>(staged + chunk_col(k0 + g) * VEC);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) r[k0 + g][e] = v[g][e] * r[k0 + g][e];
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
-    // Scale vectors that are not staged in LDS (the per-sample vector b always; a / c when they are per-sample, f64,
-    // or the launch is small) are fetched from L2 where they are used -- AFTER the transform in front of them -- and consumed chunk by chunk
-    // (the scheduler keeps as many loads in flight as the register budget allows).  Requesting a whole vector before
-    // the transform to hide its latency -- the first design -- keeps 64 more registers live across ~1000 butterfly
-    // instructions: 184-202 VGPRs = 2 waves per SIMD instead of 3-4, which costs far more than the exposed round trip.
-    auto scale_chunkwise = [&](const T *vec, bool per_sample) {
+    // Scale vectors that are not staged in LDS (the per-sample vector b unless the block has one sample; a / c when they
+    // are per-sample in (batch, sample, D) order, or the launch is small) are fetched from L2 where they are used -- AFTER
+    // the transform in front of them (requesting a whole vector before the transform keeps 64 more registers live across
+    // ~1000 butterfly instructions: 184-202 VGPRs = 2 waves per SIMD).  Round 3: even so, a whole vector in flight next
+    // to the tile is 64 + 64 registers plus addressing -- 134-146 VGPRs, THREE waves per SIMD -- so five eighths of
+    // the chunks are requested up front and the rest only when as many of the first ones have been multiplied in and
+    // their registers are free: 64 + 40 registers, FOUR waves per SIMD, at the price of a second (short, mostly
+    // overlapped) wait per vector.  Tiles of 128 data registers (one f64 row of 4096 per wave) do the same to stay within the 256
+    // registers that two waves per SIMD allow (round 2: 256 VGPRs + 76 AGPRs, one wave, 2.9 TB/s).
+    constexpr bool BIG_TILE = K * VEC * (int)sizeof(A) / 4 > 64;      // one f64 row of 4096 per wave: 128 data registers
+    // how much up front, measured per shape (tools/ab_fused_r03.sh, 4 GiB in place, interleaved builds; TB/s for 5/8, 6/8
+    // and all of the vector up front): f32 with three L2 vectors D = 512 5.67 / 5.72 / 5.87, D = 2048 5.61 / 5.64 / 5.75,
+    // D = 4096 5.42 / 5.44 / 5.22; f64 D = 512 5.53 / 5.59 / 5.42, D = 2048 5.38 / 5.41 / 5.19; one f64 row of 4096 per
+    // wave with a / c staged (only b comes from L2) 5.72 / 5.79 / 5.91.
+    constexpr int EIGHTHS = WHVI_FUSED_UPFRONT_8THS > 0 ? WHVI_FUSED_UPFRONT_8THS
+                          : (BIG_TILE && STAGE != STAGE_NONE) ? 8
+                          : (sizeof(A) == 4 && STAGE == STAGE_NONE && LOG2D <= 11) ? 8
+                          : (STAGE == STAGE_NONE ? 6 : 5);
+    constexpr int UPFRONT = K >= 4 ? (K * EIGHTHS) / 8 : K;
+    constexpr int LATE = K - UPFRONT;
+    auto scale_chunkwise = [&](const T *vec, bool per_sample) __attribute__((always_inline)) {
+        RowBases rb;
+        if constexpr (UNIFORM) rb = row_bases(vec, per_sample);
+        if constexpr (K >= 4 && AXIS == WHVI_AXIS_COL && LATE > 0) {
+            A v[K][VEC];
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            uint32_t vec_base = 0;
-            if (per_sample)
-                vec_base = sample_index(chunk_row(k)) * (AXIS == WHVI_AXIS_COL ? (1u << LOG2D) : by_group_rows.d);
-            A v[VEC];
-            scale(vec, vec_base, k, v);
+            for (int k = 0; k < UPFRONT; ++k) scale(vec, per_sample, rb, k, v[k]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) r[k][e] = v[e] * r[k][e];
+            for (int k = 0; k < LATE; ++k)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) r[k][e] = v[k][e] * r[k][e];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = UPFRONT; k < K; ++k) scale(vec, per_sample, rb, k, v[k]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = LATE; k < K; ++k)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) r[k][e] = v[k][e] * r[k][e];
+        } else {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                A v[VEC];
+                scale(vec, per_sample, rb, k, v);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) r[k][e] = v[e] * r[k][e];
+            }
         }
     };
 
-    // ---- load (or synthesise) + first scale
+    // ---- unpack (or synthesise) + first scale
     if constexpr (EYE) {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
@@ -759,72 +888,26 @@ fused_shs_kernel(u32x4 *dst, const u32x4 *src, const T *a, const T *b, const T *
             for (int e = 0; e < VEC; ++e) r[k][e] = (chunk_col(k) * VEC + e == i) ? cv : (A)0;
         }
     } else {
-        u32x4 raw[K];
-        if (full) {
 #pragma unroll
-            for (int k = 0; k < K; ++k) raw[k] = ld16<NT>(src + base + k * 64 + lane);
-        } else {
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                u32x4 z = {0u, 0u, 0u, 0u};
-                raw[k] = (base + k * 64 + lane < n_chunks) ? ld16<NT>(src + base + k * 64 + lane) : z;
-            }
-        }
-        if constexpr (STAGE_AC) {
-#pragma unroll
-            for (int k = 0; k < K; ++k) E::unpack(raw[k], r[k]);
-            if (c != nullptr) apply_staged(lds_c);
-        } else {
-#pragma unroll
-            for (int k = 0; k < K; ++k) E::unpack(raw[k], r[k]);
-            if (c != nullptr) scale_chunkwise(c, c_per_sample);     // its loads do not depend on the data: issued beside it
+        for (int k = 0; k < K; ++k) E::unpack(raw[k], r[k]);
+        if (c != nullptr) {
+            if constexpr (STAGE != STAGE_NONE) apply_staged(lds_c);
+            else scale_chunkwise(c, c_per_sample);
         }
     }
-    // Tiles of more than 64 data registers (one f64 row of 4096 per wave) run at one wave per SIMD whatever is done
-    // here, so nothing but the wave itself can hide a scale vector's L2 round trip: there the vector IS requested
-    // before the transform in front of it (2.7 vs 2.4 TB/s).
-    constexpr bool AHEAD = (K * VEC * (int)sizeof(A) / 4 > 64) && !STAGE_AC;
-    A ahead[AHEAD ? K : 1][VEC];
-    auto fetch_ahead = [&](const T *vec, bool per_sample) {
-#pragma unroll
-        for (int k = 0; k < (AHEAD ? K : 0); ++k) {
-            uint32_t vec_base = 0;
-            if (per_sample)
-                vec_base = sample_index(chunk_row(k)) * (AXIS == WHVI_AXIS_COL ? (1u << LOG2D) : by_group_rows.d);
-            scale(vec, vec_base, k, ahead[k]);
-        }
-    };
-    auto apply_ahead = [&]() {
-#pragma unroll
-        for (int k = 0; k < (AHEAD ? K : 0); ++k)
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) r[k][e] = ahead[k][e] * r[k][e];
-    };
-    if constexpr (AHEAD) {
-        if (b != nullptr) fetch_ahead(b, true);
-        transform(r, IC<0>{});
-        if (b != nullptr) apply_ahead();
-        if (a != nullptr) fetch_ahead(a, a_per_sample);
-        transform(r, IC<1>{});
-        if (a != nullptr) apply_ahead();
-    } else {
-        transform(r, IC<0>{});
-        if (b != nullptr) scale_chunkwise(b, true);
-        transform(r, IC<1>{});
-        if (a != nullptr) {
-            if constexpr (STAGE_AC) apply_staged(lds_a);
-            else scale_chunkwise(a, a_per_sample);
-        }
+    transform(r, IC<0>{});
+    if (b != nullptr) {
+        if constexpr (STAGE == STAGE_ABC) apply_staged(lds_b);
+        else scale_chunkwise(b, true);
+    }
+    transform(r, IC<1>{});
+    if (a != nullptr) {
+        if constexpr (STAGE != STAGE_NONE) apply_staged(lds_a);
+        else scale_chunkwise(a, a_per_sample);
     }
     if constexpr (NT) __syncthreads();          // the block's 4 waves write their 64 KiB back together
-    if (NT && full) {
 #pragma unroll
-        for (int k = 0; k < K; ++k) tile_store_stream(dst + base, lane, k, E::pack(r[k]), TILE * 16);
-    } else {
-#pragma unroll
-        for (int k = 0; k < K; ++k)
-            if (chunk_ok(k)) st16<NT>(dst + base + k * 64 + lane, E::pack(r[k]));
-    }
+    for (int k = 0; k < K; ++k) uniform_st16<NT>(dst + base, tile_bytes, lane, k * 1024, E::pack(r[k]));
 }
 
 // Rows shorter than one 16-byte chunk (D = 1, 2 for f32; D = 1 for f64): one thread per row, same

@@ -14,7 +14,7 @@
 #define WHVI_TUNE_ENV(name) ((const char *)nullptr)
 #if defined(WHVI_F16_UNPACK) || defined(WHVI_F16_PACK_EXP) || defined(WHVI_BF16_PACK) || defined(WHVI_ROWS_WAVES_PER_EU) || \
     defined(WHVI_ROWS_PKMASK) || defined(WHVI_FUSED_PKMASK) || defined(WHVI_FUSED_SIGNED) || defined(WHVI_EXP_UNFUSED_DPP) || \
-    defined(WHVI_NO_PK) || defined(WHVI_BLOCK_TRACE)
+    defined(WHVI_NO_PK) || defined(WHVI_BLOCK_TRACE) || defined(WHVI_VEC_AUX) || defined(WHVI_FUSED_UPFRONT_8THS)
 #error "kernel tuning switches need -DWHVI_TUNING_BUILD (make -C whvi_amd/csrc tuning DEFS=-D...)"
 #endif
 #endif
@@ -37,4 +37,11 @@
 #endif
 #ifndef WHVI_FUSED_SIGNED
 #define WHVI_FUSED_SIGNED 1        // fused kernel: signed DPP lane stages
+#endif
+#ifndef WHVI_VEC_AUX
+#define WHVI_VEC_AUX 0             // cache-policy bits of the scale-vector loads that come from L2 (0 = default, cached in L1)
+#endif
+#ifndef WHVI_FUSED_UPFRONT_8THS
+#define WHVI_FUSED_UPFRONT_8THS 0  // eighths of an L2-sourced scale vector requested before any of it is consumed (8 = all);
+                                   // 0 = the per-shape choice of fused_shs_kernel
 #endif
