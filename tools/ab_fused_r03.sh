@@ -1,5 +1,5 @@
-set -e
+# tools/ab_fused_r03.sh -- A/B of fused-kernel build variants (make -C whvi_amd/csrc tuning TAG=ab_<name> DEFS=-D...), each in
+# its own process on the same shapes (tools/probe_fused_inst.py); run on the GPU box: bash tools/ab_fused_r03.sh
 python tools/probe_fused_inst.py batch-major,sample-major > gpurun_out/r03_ab_prod.log 2>&1
-for t in aux1 aux16 aux2 up8 up6; do WHVI_HIP_LIB=whvi_amd/_exp/libwhvi_hip_$t.so python tools/probe_fused_inst.py batch-major > gpurun_out/r03_ab_$t.log 2>&1; done
-for tune in 0011 0013 0010; do WHVI_FUSED_TUNE=$tune WHVI_HIP_LIB=whvi_amd/_exp/libwhvi_hip_tuning.so python tools/probe_fused_inst.py sample-major > gpurun_out/r03_ab_tune$tune.log 2>&1; done
-for f in prod aux1 aux16 aux2 up8 up6 tune0011 tune0013 tune0010; do echo "== $f"; grep -E "^float" gpurun_out/r03_ab_$f.log | awk '{print $1, $2, $3, $4, $5, $6, $9, $12, $NF}' | cut -c1-150; done
+for lib in whvi_amd/_exp/libwhvi_hip_ab_*.so; do t=$(basename $lib .so); t=${t#libwhvi_hip_ab_}; WHVI_HIP_LIB=$lib python tools/probe_fused_inst.py batch-major,sample-major > gpurun_out/r03_ab_$t.log 2>&1; done
+for f in gpurun_out/r03_ab_*.log; do echo "== $f"; grep -E "^float" $f | awk '{print $1, $2, $3, $4, $5, $6, $9, $12, $NF}' | cut -c1-150; done

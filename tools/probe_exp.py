@@ -10,11 +10,12 @@ SFX = sys.argv[2] if len(sys.argv) > 2 else "f32"           # f32 | f16 | bf16 |
 DT = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16, "i32": torch.int32}[SFX]
 x = (torch.randn(1 << 30 if LOG2D < 12 else 1 << 32, device="cuda") * 2.0 ** -100).to(DT).view(-1, 1 << LOG2D)
 libs = {"prod": _hip.lib()}
-for path in sorted(glob.glob(os.path.join(os.path.dirname(_hip.LIB_PATH), "_exp", "libexp_*.so"))):
+for path in sorted(glob.glob(os.path.join(os.path.dirname(_hip.LIB_PATH), "_exp", "libexp_*.so")) +
+                   glob.glob(os.path.join(os.path.dirname(_hip.LIB_PATH), "_exp", "libwhvi_hip_ab_*.so"))):
     L = ctypes.CDLL(path)
     getattr(L, 'whvi_fwht_' + SFX).restype = ctypes.c_int
     getattr(L, 'whvi_fwht_' + SFX).argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p]
-    libs[os.path.basename(path)[7:-3]] = L
+    libs[os.path.basename(path)[:-3].replace("libexp_", "").replace("libwhvi_hip_ab_", "")] = L
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

@@ -225,6 +225,23 @@ __device__ __forceinline__ void tile_store_stream(u32x4 *tile_base, int lane, in
     __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, lane * 16 + k * 1024, 0, (1 << 4) | (1 << 1));
 }
 
+// 16-byte load at (wave-uniform base pointer) + lane * 16 + byte offset: a raw buffer load with the base in SGPRs -- no
+// 64-bit VGPR address arithmetic per chunk and no address registers (the global_load form of a per-chunk pointer costs a
+// v_add_co / v_addc pair and two VGPRs each).  `bytes` bounds the access (reads beyond it return zeros).
+template <bool NT = false>
+__device__ __forceinline__ u32x4 uniform_ld16(const void *base, uint32_t bytes, int lane, int byte_offset)
+{
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, byte_offset, NT ? (1 << 1) : WHVI_VEC_AUX));
+}
+// the store counterpart; writes beyond `bytes` are dropped.  NT: write-through + non-temporal (see tile_store_stream)
+template <bool NT>
+__device__ __forceinline__ void uniform_st16(void *base, uint32_t bytes, int lane, int byte_offset, const u32x4 &v)
+{
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)bytes, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, lane * 16, byte_offset, NT ? ((1 << 4) | (1 << 1)) : 0);
+}
+
 // ---- batched row FWHT ------------------------------------------------------------------------
 // dst/src: n_chunks 16-byte chunks; tile t = chunks [t*64*K, (t+1)*64*K).  Only the last tile
 // can be partial; its missing chunks belong to rows that do not exist (rows never straddle
@@ -279,6 +296,24 @@ fwht_rows_kernel(u32x4 *dst, const u32x4 *src, int64_t n_chunks, int64_t n_tiles
             fwht_tile<A, VEC, K, LOG2D, POLICY, WHVI_ROWS_PKMASK>(r, lane);      // no explicit packed adds here: see fwht_tile
     };
 
+#if defined(WHVI_TUNING_BUILD) && defined(WHVI_ROWS_BUFFER_IO)
+    // A/B: bounds-checked buffer accesses from the tile's wave-uniform base (the fused kernel's form) -- no full / partial
+    // branch, no per-chunk addresses
+    auto tile_bytes_of = [&](int64_t tile) -> uint32_t {
+        const int64_t base = tile * TILE;
+        return (uint32_t)((n_chunks - base < TILE ? n_chunks - base : (int64_t)TILE) * 16);
+    };
+    auto load_tile = [&](int64_t tile, u32x4 (&raw)[K]) {
+        const uint32_t bytes = tile_bytes_of(tile);
+#pragma unroll
+        for (int k = 0; k < K; ++k) raw[k] = uniform_ld16<NT>(src + tile * TILE, bytes, lane, k * 1024);
+    };
+    auto store_tile = [&](int64_t tile, A (&r)[K][VEC]) {
+        const uint32_t bytes = tile_bytes_of(tile);
+#pragma unroll
+        for (int k = 0; k < K; ++k) uniform_st16<NT>(dst + tile * TILE, bytes, lane, k * 1024, E::pack(r[k]));
+    };
+#else
     auto load_tile = [&](int64_t tile, u32x4 (&raw)[K]) {
         const int64_t base = tile * TILE;
         const u32x4 *p = src + base + lane;
@@ -311,6 +346,7 @@ fwht_rows_kernel(u32x4 *dst, const u32x4 *src, int64_t n_chunks, int64_t n_tiles
         }
     };
 
+#endif
     if constexpr (!PREFETCH) {
         // plain grid-stride form: with grid == tiles/waves this is one tile per wave and out; only
         // one tile's worth of registers is ever live (fits a 1024-thread block at 128 VGPRs)
@@ -643,23 +679,6 @@ inline FastDiv make_fastdiv(uint32_t d)
 //   STAGE_ABC   a, b and c of the block's one sample (same condition): no scale vector comes through L2 -> L1 at all.
 constexpr int STAGE_NONE = 0, STAGE_AC = 1, STAGE_ABC = 3;
 
-// 16-byte load at (wave-uniform base pointer) + lane * 16 + byte offset: a raw buffer load with the base in SGPRs -- no
-// 64-bit VGPR address arithmetic per chunk and no address registers (the global_load form of a per-chunk pointer costs a
-// v_add_co / v_addc pair and two VGPRs each).  `bytes` bounds the access (reads beyond it return zeros).
-template <bool NT = false>
-__device__ __forceinline__ u32x4 uniform_ld16(const void *base, uint32_t bytes, int lane, int byte_offset)
-{
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
-    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, byte_offset, NT ? (1 << 1) : WHVI_VEC_AUX));
-}
-// the store counterpart; writes beyond `bytes` are dropped.  NT: write-through + non-temporal (see tile_store_stream)
-template <bool NT>
-__device__ __forceinline__ void uniform_st16(void *base, uint32_t bytes, int lane, int byte_offset, const u32x4 &v)
-{
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)bytes, 0x00020000);
-    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, lane * 16, byte_offset, NT ? ((1 << 4) | (1 << 1)) : 0);
-}
-
 template <typename T, int LOG2D, int K, int AXIS, bool EYE, bool NT, int BLOCK, int POLICY = POLICY_DPP,
           int STAGE = STAGE_NONE>
 __global__ void __launch_bounds__(BLOCK)
@@ -733,8 +752,29 @@ fused_shs_kernel(u32x4 *dst, const u32x4 *src, const T *a, const T *b, const T *
     const uint32_t tile_bytes = active ? (uint32_t)((n_chunks - base < TILE ? n_chunks - base : (int64_t)TILE) * 16) : 0u;
     u32x4 raw[EYE ? 1 : K];
     if constexpr (!EYE) {
+#if defined(WHVI_TUNING_BUILD) && WHVI_FUSED_TILE_LOADS == 2   /* timing experiment only: every tile taken to be full (WRONG on ragged tails) */
+        if (active) {
 #pragma unroll
-        for (int k = 0; k < K; ++k) raw[k] = uniform_ld16<NT>(src + base, tile_bytes, lane, k * 1024);
+            for (int k = 0; k < K; ++k) raw[k] = ld16<NT>(src + base + k * 64 + lane);
+        }
+        if (false)
+#else
+        // Full tiles of 4-byte elements (and short f64 rows): plain global loads behind a wave-uniform branch -- on a bare
+        // stream buffer loads are 10 % slower than global loads (5.84 vs 6.48 TB/s on the plain transform) and here
+        // 1-3.5 % (f32 D = 512 / 2048 / 4096: shared a / c 6.44 / 6.39 / 6.32 vs 6.37 / 6.38 / 6.31 TB/s, three L2 vectors
+        // 5.98 / 5.92 / 5.54 vs 5.84 / 5.72 / 5.42); f64 rows of 2048 and 4096 lose with them (6.18 vs 6.25, and 3.8 vs
+        // 5.95: the branch costs the 128-register tile its second wave per SIMD) and keep the bounds-checked buffer loads,
+        // as do the partial last tile and idle waves everywhere.  gpurun_out r03_ab_{prod,tl1,tl2}.log
+        constexpr bool GLOBAL_TILE_LOADS = WHVI_FUSED_TILE_LOADS >= 0 ? WHVI_FUSED_TILE_LOADS == 1 : (sizeof(A) == 4 || LOG2D <= 10);
+        if (GLOBAL_TILE_LOADS && tile_bytes == TILE * 16) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) raw[k] = ld16<NT>(src + base + k * 64 + lane);
+        } else
+#endif
+        {
+#pragma unroll
+            for (int k = 0; k < K; ++k) raw[k] = uniform_ld16<NT>(src + base, tile_bytes, lane, k * 1024);
+        }
     }
     if constexpr (STAGE != STAGE_NONE) {
         __builtin_amdgcn_sched_barrier(0);

@@ -14,7 +14,7 @@
 #define WHVI_TUNE_ENV(name) ((const char *)nullptr)
 #if defined(WHVI_F16_UNPACK) || defined(WHVI_F16_PACK_EXP) || defined(WHVI_BF16_PACK) || defined(WHVI_ROWS_WAVES_PER_EU) || \
     defined(WHVI_ROWS_PKMASK) || defined(WHVI_FUSED_PKMASK) || defined(WHVI_FUSED_SIGNED) || defined(WHVI_EXP_UNFUSED_DPP) || \
-    defined(WHVI_NO_PK) || defined(WHVI_BLOCK_TRACE) || defined(WHVI_VEC_AUX) || defined(WHVI_FUSED_UPFRONT_8THS)
+    defined(WHVI_NO_PK) || defined(WHVI_BLOCK_TRACE) || defined(WHVI_VEC_AUX) || defined(WHVI_FUSED_UPFRONT_8THS) || defined(WHVI_ROWS_BUFFER_IO) || defined(WHVI_FUSED_TILE_LOADS)
 #error "kernel tuning switches need -DWHVI_TUNING_BUILD (make -C whvi_amd/csrc tuning DEFS=-D...)"
 #endif
 #endif
@@ -44,4 +44,9 @@
 #ifndef WHVI_FUSED_UPFRONT_8THS
 #define WHVI_FUSED_UPFRONT_8THS 0  // eighths of an L2-sourced scale vector requested before any of it is consumed (8 = all);
                                    // 0 = the per-shape choice of fused_shs_kernel
+#endif
+#ifndef WHVI_FUSED_TILE_LOADS
+#define WHVI_FUSED_TILE_LOADS -1   // fused kernel, full tiles: -1 = per shape (kernels.hpp), 0 = bounds-checked buffer loads for every
+                                   // tile (branch-free), 1 = global loads for full tiles behind a branch, 2 (tuning, WRONG on
+                                   // ragged tails) = global loads without checks
 #endif
