@@ -552,6 +552,21 @@ def _extra_toy(device):
                     "unspecified CUDA GPU"}
 
 
+def _extra_config4_train(device):
+    """BASELINE config 4's network under the reference's own training recipe (``train_model`` + ``make_optimizer``:
+    src/networks.py:71-99, src/evaluation.py:15-27): ms per optimisation step for the eager loop, the packed parameter
+    layout, and ``train_model(graphed=True)`` -- one hipGraph replay per step with the learning-rate schedule inside.
+    A child process (tools/config4_train_step.py) with its exit code in the line."""
+    import subprocess
+    child = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "config4_train_step.py")],
+                           capture_output=True, text=True, timeout=600)
+    line = [ln for ln in child.stdout.splitlines() if ln.startswith("{")]
+    out = json.loads(line[-1]) if line else {"error": child.stderr.strip().splitlines()[-3:]}
+    out["child_exit_code"] = child.returncode
+    out["recipe"] = "train_model two phases, Adam + LambdaLR stepped after every batch, batch 256, 1 MC sample, with KL"
+    return out
+
+
 def extras(device):
     """Secondary measurements (inputs resident, HIP-event timed).  Every section is independent: a failure is
     recorded under its own key and never costs the other numbers or the headline line."""
@@ -562,7 +577,8 @@ def extras(device):
                     ("wbar_fwd", _extra_wbar_fwd),
                     ("wbar_bwd", _extra_wbar_bwd),
                     ("whvilinear_512_fwd_kl_32mc_b4096", _extra_layer),
-                    ("whviregression_3_1024_1024_1_mc16", _extra_network), ("toy_regression", _extra_toy)):
+                    ("whviregression_3_1024_1024_1_mc16", _extra_network), ("toy_regression", _extra_toy),
+                    ("config4_train_step", _extra_config4_train)):
         try:
             out[key] = fn(device)
         except Exception as err:

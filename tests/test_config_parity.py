@@ -286,6 +286,95 @@ def test_train_trajectory_vs_reference_gpu(run, mode, monkeypatch, tmp_path, hip
     run_train_trajectory(run, "cuda", monkeypatch, tmp_path, mode, 1e-5, 1e-5, 2e-2)
 
 
+def test_device_resident_schedule_is_the_reference_schedule():
+    """``make_optimizer(capturable=True)``'s ``DeviceLambdaLR`` (state in tensors, ``step()`` = device ops only) follows the
+    recorded learning rates of the reference's ``LambdaLR`` (src/evaluation.py:25-26) to float32 resolution -- here on
+    host tensors; the GPU trajectory test below runs it inside the captured step."""
+    from whvi_amd.evaluation import DeviceLambdaLR
+    g = _npz("train_golden.npz")
+    for run, lam0 in (("default", 0.001), ("fast", 0.05)):
+        net = nn.Linear(2, 2)
+        opt = torch.optim.Adam(net.parameters(), lr=torch.tensor(lam0), foreach=False)
+        sched = DeviceLambdaLR(opt, lambda t: lam0 * torch.pow(1.0 + 0.0005 * t, -0.3), base_lrs=[lam0])
+        want = g[f"{run}/lr"]
+        for i in range(len(want)):
+            assert torch.is_tensor(opt.param_groups[0]["lr"])
+            assert abs(sched.get_last_lr()[0] - want[i]) <= 2e-7 * want[i], (run, i)
+            sched.step()
+        state = sched.state_dict()
+        sched.load_state_dict({"t": 3.0, "base_lrs": state["base_lrs"]})
+        assert abs(sched.get_last_lr()[0] - want[3]) <= 2e-7 * want[3]
+    host = torch.optim.lr_scheduler.LambdaLR(torch.optim.Adam(nn.Linear(2, 2).parameters(), lr=1.0), lambda t: 1.0)
+    from whvi_amd.graphs import GraphedTrainStep
+    assert not getattr(host, "device_resident", False) and DeviceLambdaLR.device_resident and GraphedTrainStep is not None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("packed", [False, True])
+@pytest.mark.parametrize("run", ["default", "fast"])
+def test_train_trajectory_graphed_vs_reference_gpu(run, packed, tmp_path, hip_lib):
+    """The reference's training recipe on the FAST path: ``train_model(graphed=True)`` -- both phases,
+    ``scheduler.step()`` after every batch (src/networks.py:80-81), the checkpoint of phase 2 -- with every step one
+    hipGraph replay holding loss, backward, Adam and the schedule (learning rate and step counter in device memory).
+    The two recorded runs of the reference's ``train_model`` + ``make_optimizer`` are replayed through it with the recorded
+    eps injected into the layers' static buffers: learning rates equal to float32 resolution, every loss within 1e-5,
+    final state and ``epoch-0.pth`` inside the 2 % movement bound of the eager GPU test, reference ``state_dict`` keys --
+    also with the packed parameter layout."""
+    import ast
+    g = _npz("train_golden.npz")
+    S = 2
+    net = WHVIRegression([WHVILinear(3, 16, lambda_=3.0), nn.ReLU(), WHVILinear(16, 16, lambda_=3.0), nn.ReLU(),
+                          WHVILinear(16, 1, lambda_=3.0)], train_samples=S, eval_samples=4)
+    init = {k[len(f"{run}/init."):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(f"{run}/init.")}
+    net.load_state_dict(init)
+    net = net.to("cuda")
+    X, Y = torch.from_numpy(g[f"{run}/X"]).to("cuda"), torch.from_numpy(g[f"{run}/Y"]).to("cuda")
+    loader = DataLoader(TensorDataset(X, Y), batch_size=8)
+    optimizer, scheduler = make_optimizer(net, **ast.literal_eval(str(g[f"{run}/optimizer_kwargs"])), capturable=True,
+                                          packed=packed)
+    assert len(list(net.parameters())) == (13 if packed else 25)
+    epochs1, epochs2 = (int(v) for v in g[f"{run}/epochs"])
+    steps = len(g[f"{run}/loss"])
+    tables = [g[f"{run}/eps_layer{k}"] for k in range(3)]                 # (steps, S, J, D)
+    seen = {"i": 0, "lr": [], "loss": []}
+
+    def before_replay(step):
+        i = seen["i"]
+        if i > 0:
+            seen["loss"].append(float(step.static_loss))                  # the previous replay's loss
+        assert len(step.eps_buffers) == 3
+        for buf, table in zip(step.eps_buffers, tables):
+            buf.copy_(torch.from_numpy(np.ascontiguousarray(np.swapaxes(table[i], 0, 1))))
+        seen["lr"].append(float(optimizer.param_groups[0]["lr"]))
+        seen["i"] = i + 1
+    before = {k: v.clone() for k, v in net.state_dict().items()}
+    step = net.train_model(loader, optimizer, scheduler, epochs1=epochs1, epochs2=epochs2, checkpoint_dir=tmp_path,
+                           graphed=True, packed=packed, graph_options={"static_eps": True, "before_replay": before_replay})
+    seen["loss"].append(float(step.static_loss))
+    assert seen["i"] == steps and not net.training
+    assert float(scheduler.t) == steps, "the schedule advanced once per replay and never during the capture warm-up"
+    assert all(torch.equal(init[k].to("cuda"), before[k]) for k in init)
+    want_lr = g[f"{run}/lr"]
+    assert np.abs(np.array(seen["lr"]) - want_lr).max() <= 2e-7 * want_lr.max(), "learning-rate schedule"
+    want, got = g[f"{run}/loss"], np.array(seen["loss"])
+    assert abs(got[0] - want[0]) <= 1e-5 * abs(want[0]), (got[0], want[0])
+    assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max(), np.abs(got - want).max()
+
+    def close_state(state, prefix):
+        keys = [k[len(prefix):] for k in g.files if k.startswith(prefix)]
+        assert set(keys) == set(state), "the reference's state_dict keys"
+        for k in keys:
+            ref, start = g[prefix + k].astype(np.float64), g[f"{run}/init.{k}"].astype(np.float64)
+            ours = state[k].detach().cpu().numpy().astype(np.float64)
+            moved = max(np.abs(ref - start).max(), float(np.sum(g[f"{run}/lr"])))
+            assert np.abs(ours - ref).max() <= 2e-2 * moved + 4e-7 * np.abs(ref).max(), (prefix + k, np.abs(ours - ref).max(), moved)
+    close_state(net.state_dict(), f"{run}/final.")
+    assert sorted(os.listdir(tmp_path)) == ["epoch-0.pth"]
+    close_state(torch.load(tmp_path / "epoch-0.pth"), f"{run}/ckpt_epoch0.")
+    # the layers have their generator back: a later eager pass draws fresh eps
+    assert all(getattr(m, "_eps_static", None) is None for m in net.modules())
+
+
 # ---- configs 2, 3, 5 at their full sizes (GPU) ----------------------------------------------------------------
 def _bits(a):
     return a.view({2: np.uint16, 4: np.uint32, 8: np.uint64}[a.dtype.itemsize])

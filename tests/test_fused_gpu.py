@@ -473,12 +473,63 @@ def test_graphed_train_step_rejects_a_stale_autograd_graph(hip_lib):
         kept.append(loss)
         opt.step()
     torch.cuda.synchronize()
+    params = {k: v.detach().clone() for k, v in net.named_parameters()}
+    adam_steps = [float(opt.state[p]["step"]) for p in net.parameters()]
     with pytest.raises(RuntimeError, match="autograd graph of an earlier pass is still alive"):
         GraphedTrainStep(net, opt, x, y, n=64)
+    # the error is raised BEFORE the warm-up -- nothing of the training state has moved
+    assert all(torch.equal(v.detach(), params[k]) for k, v in net.named_parameters())
+    assert [float(opt.state[p]["step"]) for p in net.parameters()] == adam_steps
     kept.clear()
     del loss
     step = GraphedTrainStep(net, opt, x, y, n=64)
     assert torch.isfinite(step(x, y))
+
+
+def test_building_a_graphed_train_step_has_no_side_effects(hip_lib):
+    """the capture warm-up used to leave max(1, warmup) real optimizer steps behind.  Now parameters, Adam's
+    moments and step counts, the learning-rate schedule, the device generator and the in-kernel Philox states are put
+    back: building the step changes nothing, on a fresh optimizer (whose lazily created state must read as zero) and on
+    one that has trained; the first replay then equals the first eager step of an identical twin."""
+    import copy
+    import torch.nn as nn
+    from whvi_amd.evaluation import make_optimizer
+    from whvi_amd.graphs import GraphedTrainStep
+    from whvi_amd.networks import WHVIRegression
+    torch.manual_seed(3)
+    net = WHVIRegression([WHVILinear(3, 16, lambda_=1.0), nn.Tanh(), WHVILinear(16, 16, lambda_=1.0), nn.Tanh(),
+                          WHVILinear(16, 1, lambda_=1.0)], train_samples=2).to(DEV).train()
+    twin = copy.deepcopy(net)
+    x, y = torch.randn(32, 3, device=DEV), torch.randn(32, 1, device=DEV)
+    opt, sched = make_optimizer(net, lambda0=0.05, capturable=True)
+    opt2, sched2 = make_optimizer(twin, lambda0=0.05, capturable=True)
+    before = {k: v.detach().clone() for k, v in net.named_parameters()}
+    rng = torch.cuda.get_rng_state(torch.device(DEV))
+    step = GraphedTrainStep(net, opt, x, y, n=320, scheduler=sched, warmup=3)
+    assert all(torch.equal(v.detach(), before[k]) for k, v in net.named_parameters())
+    assert float(sched.t) == 0.0 and abs(sched.get_last_lr()[0] - 0.05 * 0.05) < 1e-9
+    assert torch.equal(torch.cuda.get_rng_state(torch.device(DEV)), rng)
+    for p in net.parameters():
+        st = opt.state[p]
+        assert float(st["step"]) == 0.0 and float(st["exp_avg"].abs().max()) == 0.0 and float(st["exp_avg_sq"].abs().max()) == 0.0
+    # first replay == first eager step of the twin (same parameters, same generator state -> same eps)
+    torch.cuda.set_rng_state(rng, torch.device(DEV))
+    loss_graph = float(step(x, y))
+    torch.cuda.set_rng_state(rng, torch.device(DEV))
+    opt2.zero_grad(set_to_none=True)
+    loss_eager = twin.loss(x, y, n=320)
+    loss_eager.backward()
+    opt2.step()
+    sched2.step()
+    assert abs(loss_graph - float(loss_eager)) <= 1e-6 * abs(float(loss_eager))
+    for (k, a), (_, b) in zip(net.named_parameters(), twin.named_parameters()):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-7), k
+    assert float(sched.t) == 1.0 and abs(sched.get_last_lr()[0] - sched2.get_last_lr()[0]) < 1e-12
+    # a host-side schedule is refused, with the remedy in the message
+    host = torch.optim.lr_scheduler.LambdaLR(torch.optim.Adam(twin.parameters(), lr=1e-3, capturable=True), lambda t: 1.0)
+    del loss_eager
+    with pytest.raises(RuntimeError, match="DeviceLambdaLR"):
+        GraphedTrainStep(twin, opt2, x, y, n=320, scheduler=host)
 
 
 def test_reparam_kl_double_backward_vs_torch_ops(hip_lib):

@@ -6,9 +6,10 @@ capture-safe (no allocation, no synchronisation, launches on the stream it is gi
 pass can be recorded once into a hipGraph (``torch.cuda.graph``) and replayed: one launch per forward.
 torch's generator is graph-aware, so every replay draws fresh eps.
 
-``GraphedTrainStep`` does the same for a whole training step (loss, backward, optimizer): the backward of the
-fused weight kernel runs from the autograd engine's thread and is captured with the rest
-(tools/graph_train_probe.py walks through the stages).
+``GraphedTrainStep`` does the same for a whole training step (loss, backward, optimizer, learning-rate schedule): the
+backward of the fused weight kernel runs from the autograd engine's thread and is captured with the rest
+(tools/graph_train_probe.py walks through the stages); ``WHVINetwork.train_model(..., graphed=True)`` runs the
+reference's two-phase recipe on it.
 """
 import gc
 import warnings
@@ -48,45 +49,116 @@ class GraphedPredictor:
         return self.static_out
 
 
-class GraphedTrainStep:
-    """One optimisation step of a ``WHVINetwork`` -- ``loss(x, y, n)``, ``backward()``, ``optimizer.step()`` --
-    recorded into a hipGraph and replayed: ``loss = step(x, y)``.
+def _reaches(root, wanted, limit=200_000):
+    """True when the autograd graph under ``root`` (a grad_fn) contains the gradient accumulator of one of ``wanted``
+    (a set of parameter ids)."""
+    seen, stack = set(), [root]
+    while stack and len(seen) < limit:
+        node = stack.pop()
+        if node is None or id(node) in seen:
+            continue
+        seen.add(id(node))
+        variable = getattr(node, "variable", None)                 # AccumulateGrad nodes carry their leaf
+        if variable is not None and id(variable) in wanted:
+            return True
+        stack.extend(fn for fn, _ in node.next_functions)
+    return False
 
-    The optimizer must keep its state on the device (``torch.optim.Adam(..., capturable=True)``); learning-rate
-    schedules that change ``lr`` from the host are not captured.  ``x`` / ``y`` keep the example's shapes; the
-    returned loss is a static tensor overwritten by the next call.  Fresh eps are drawn on every replay.
+
+def _stale_graph_holders(params, device):
+    """Live tensors on ``device`` that still carry an autograd graph reaching ``params`` (a kept ``loss``, a list of
+    losses, ...).  Text-independent companion of the warning check below: found by walking the garbage collector's
+    tensors, so it does not depend on how a torch build words its stream-mismatch warning."""
+    wanted = {id(p) for p in params}
+    found = []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")                            # isinstance() on lazy module attributes may warn
+        for obj in gc.get_objects():
+            try:
+                if (isinstance(obj, torch.Tensor) and obj.grad_fn is not None and obj.device == device
+                        and _reaches(obj.grad_fn, wanted)):
+                    found.append(obj)
+            except (ReferenceError, RuntimeError):                 # objects dying under the walk
+                continue
+    return found
+
+
+class GraphedTrainStep:
+    """One optimisation step of a ``WHVINetwork`` -- ``loss(x, y, n)``, ``backward()``, ``optimizer.step()`` and, when
+    given, ``scheduler.step()`` -- recorded into a hipGraph and replayed: ``loss = step(x, y)``.
+
+    The optimizer must keep its state on the device (``torch.optim.Adam(..., capturable=True)``).  A learning-rate
+    schedule must live there too: the reference's recipe steps its ``LambdaLR`` after every batch (src/networks.py:80-81,
+    src/evaluation.py:25-26), which a host-side scheduler cannot do inside a graph; ``make_optimizer(net,
+    capturable=True)`` returns Adam with a device learning rate and a ``DeviceLambdaLR`` whose ``step()`` is captured
+    with the rest.  ``x`` / ``y`` keep the example's shapes; the returned loss is a static tensor overwritten by the
+    next call.  Fresh eps are drawn on every replay -- unless ``static_eps=True``: every WHVI layer then reads its draws
+    from a static buffer (``step.eps_buffers``, one ``(J, S, D)`` tensor per layer in module order) that the caller
+    fills before each call: how recorded trajectories are replayed through the captured step.
+
+    Building it has NO side effects on the training state: the warm-up steps that torch needs before a capture
+    (optimizer state initialised, allocator warm) run on a side stream, and parameters, optimizer state, schedule, the
+    device's generator and the in-kernel Philox states are then put back exactly where they were.  At least one warm-up
+    step always runs.
 
     It may be built after the network has trained eagerly, provided no tensor of an earlier pass that still carries
     an autograd graph (a kept ``loss``) is alive: gradient accumulators created by a backward pass on another
-    stream would make the capture abort the PROCESS inside the HIP runtime.  That precondition is checked: the
-    side-stream warm-up runs with torch's "AccumulateGrad node's stream does not match" warning promoted, and a
-    ``RuntimeError`` is raised before capture begins when it fires.  ``WHVINetwork.loss`` itself keeps only
-    detached monitoring values."""
+    stream would make the capture abort the PROCESS inside the HIP runtime.  That precondition is checked twice and a
+    ``RuntimeError`` is raised BEFORE anything is touched: live tensors whose graph reaches the network's parameters
+    are looked for directly, and the side-stream warm-up runs with torch's "AccumulateGrad node's stream does not
+    match" warning promoted as a second line.  ``WHVINetwork.loss`` itself keeps only detached monitoring values."""
 
-    def __init__(self, net, optimizer, example_x, example_y, n: int, ignore_kl: bool = False, warmup: int = 3):
+    def __init__(self, net, optimizer, example_x, example_y, n: int, ignore_kl: bool = False, warmup: int = 3,
+                 scheduler=None, static_eps: bool = False):
         if example_x.device.type != "cuda":
             raise RuntimeError("GraphedTrainStep needs GPU tensors")
         for group in optimizer.param_groups:
             if "capturable" in group and not group["capturable"]:
                 raise RuntimeError("GraphedTrainStep: create the optimizer with capturable=True")
-        self.net, self.optimizer, self.n, self.ignore_kl = net, optimizer, int(n), bool(ignore_kl)
+        if scheduler is not None and not getattr(scheduler, "device_resident", False):
+            raise RuntimeError("GraphedTrainStep: a scheduler that sets the learning rate from the host cannot be captured; "
+                               "use whvi_amd.evaluation.DeviceLambdaLR (make_optimizer(net, capturable=True))")
+        if scheduler is not None and not all(torch.is_tensor(g["lr"]) for g in optimizer.param_groups):
+            raise RuntimeError("GraphedTrainStep: with a scheduler the optimizer's learning rate must be a device tensor")
+        self.net, self.optimizer, self.scheduler = net, optimizer, scheduler
+        self.n, self.ignore_kl = int(n), bool(ignore_kl)
         self.static_x, self.static_y = example_x.detach().clone(), example_y.detach().clone()
         dev = example_x.device
+        params = [p for group in optimizer.param_groups for p in group["params"]]
         # gradient accumulators of an earlier eager backward belong to the stream that ran it; they die with the
-        # last reference to that pass's autograd graph, so drop ours before warming up on the capture side stream
+        # last reference to that pass's autograd graph, so drop ours before looking for anybody else's
         net._pass_kl = None
         for module in net.modules():
             if hasattr(module, "_mc_kl"):
                 module._mc_kl = None
         optimizer.zero_grad(set_to_none=True)
         gc.collect()
+        stale_message = (
+            "GraphedTrainStep: an autograd graph of an earlier pass is still alive (a kept `loss` tensor, a list of "
+            "losses, ...): its gradient accumulators belong to another stream and capturing a backward pass "
+            "through them would abort inside the HIP runtime. Drop those tensors (keep `loss.detach()` or "
+            "`float(loss)` instead) and build the GraphedTrainStep again.")
+        if _stale_graph_holders(params, dev):
+            raise RuntimeError(stale_message)                # nothing has been touched yet
         torch.cuda.synchronize(dev)
+        # ---- what the warm-up must not change
+        saved_params = [p.detach().clone() for p in params]
+        fresh_state = {id(p): (p not in optimizer.state or len(optimizer.state[p]) == 0) for p in params}
+        saved_state = {id(p): {k: (v.clone() if torch.is_tensor(v) else v) for k, v in optimizer.state.get(p, {}).items()}
+                       for p in params}
+        saved_lrs = [g["lr"].clone() if torch.is_tensor(g["lr"]) else g["lr"] for g in optimizer.param_groups]
+        saved_t = scheduler.t.clone() if scheduler is not None else None
+        saved_rng = torch.cuda.get_rng_state(dev)
+        philox = [(m, m._rng_state.clone()) for m in net.modules() if torch.is_tensor(getattr(m, "_rng_state", None))]
+        if static_eps:
+            for module in net.modules():
+                if hasattr(type(module), "inkernel_rng"):
+                    module._eps_static = True                # allocated by the layer's first draw (the warm-up)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
-        # A stale autograd graph (a kept ``loss`` of an earlier eager pass) keeps the parameters' AccumulateGrad nodes
-        # alive on the stream that created them; the warm-up's backward on the side stream then has to synchronise
-        # with that stream -- harmless here, a process abort inside torch.cuda.graph.  torch warns about exactly that
-        # (once per process unless warn-always is on), so the warm-up doubles as the check.
+        # A stale autograd graph keeps the parameters' AccumulateGrad nodes alive on the stream that created them; the
+        # warm-up's backward on the side stream then has to synchronise with that stream -- harmless here, a process
+        # abort inside torch.cuda.graph.  torch warns about exactly that (once per process unless warn-always is on).
         warn_always = torch.is_warn_always_enabled()
         torch.set_warn_always(True)
         try:
@@ -98,28 +170,66 @@ class GraphedTrainStep:
         finally:
             torch.set_warn_always(warn_always)
         torch.cuda.current_stream(dev).wait_stream(side)
+        # ---- put the training state back where it was
+        with torch.no_grad():
+            for p, value in zip(params, saved_params):
+                p.copy_(value)
+            for p in params:
+                state = optimizer.state.get(p, {})
+                for key, value in state.items():
+                    if not torch.is_tensor(value):
+                        continue
+                    if fresh_state[id(p)]:
+                        value.zero_()                        # what Adam's lazy initialisation would have created
+                    else:
+                        value.copy_(saved_state[id(p)][key])
+            for group, lr in zip(optimizer.param_groups, saved_lrs):
+                if torch.is_tensor(lr):
+                    group["lr"].copy_(lr)
+            if scheduler is not None:
+                scheduler.t.copy_(saved_t)
+            for module, value in philox:
+                module._rng_state.copy_(value)
+        torch.cuda.set_rng_state(saved_rng, dev)
+        self.eps_buffers = [m._eps_static for m in net.modules() if torch.is_tensor(getattr(m, "_eps_static", None))]
         stale = [w for w in caught if "AccumulateGrad node's stream" in str(w.message)]
         for w in caught:                             # everything else is passed on unchanged
             if w not in stale:
                 warnings.warn_explicit(w.message, w.category, w.filename, w.lineno)
         if stale:
             optimizer.zero_grad(set_to_none=True)
-            raise RuntimeError(
-                "GraphedTrainStep: an autograd graph of an earlier pass is still alive (a kept `loss` tensor, a list of "
-                "losses, ...): its gradient accumulators belong to another stream and capturing a backward pass "
-                "through them would abort inside the HIP runtime. Drop those tensors (keep `loss.detach()` or "
-                "`float(loss)` instead) and build the GraphedTrainStep again.")
+            raise RuntimeError(stale_message)
         self.graph = torch.cuda.CUDAGraph()
         optimizer.zero_grad(set_to_none=True)
         with torch.cuda.graph(self.graph):
             self.static_loss = net.loss(self.static_x, self.static_y, self.n, ignore_kl=self.ignore_kl)
             self.static_loss.backward()
             optimizer.step()
+            if scheduler is not None:
+                scheduler.step()
 
     def _eager_step(self):
         self.optimizer.zero_grad(set_to_none=True)
         self.net.loss(self.static_x, self.static_y, self.n, ignore_kl=self.ignore_kl).backward()
         self.optimizer.step()
+        if self.scheduler is not None:
+            self.scheduler.step()
+
+    def matches(self, x: torch.Tensor, y: torch.Tensor) -> bool:
+        return x.shape == self.static_x.shape and y.shape == self.static_y.shape and x.dtype == self.static_x.dtype
+
+    def release_static_eps(self):
+        """Give the layers their generator back (the captured graph keeps reading the static buffers)."""
+        self._eps_owners = [(m, m._eps_static) for m in self.net.modules()
+                            if torch.is_tensor(getattr(m, "_eps_static", None))] or getattr(self, "_eps_owners", [])
+        for module in self.net.modules():
+            if getattr(module, "_eps_static", None) is not None:
+                module._eps_static = None
+
+    def restore_static_eps(self):
+        """Undo ``release_static_eps`` (eager steps beside the graph read the same buffers again)."""
+        for module, buf in getattr(self, "_eps_owners", []):
+            module._eps_static = buf
 
     def __call__(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
         if x.shape != self.static_x.shape or y.shape != self.static_y.shape:

@@ -128,33 +128,81 @@ class WHVINetwork(nn.Module, WHVI):
         return mnll if ignore_kl else mnll + kl
 
     def _epochs(self, data_loader, optimizer, scheduler, epochs, label, ignore_kl, pbar_update_period,
-                checkpoint_dir=None, set_to_none=False):
+                checkpoint_dir=None, set_to_none=False, graphed=None):
         bar = _progress(range(epochs), f'[{label}] KL = {self.current_kl:.2f}, MNLL = {self.current_mnll:.2f}')
+        n = len(data_loader.dataset)
         for epoch in bar:
             for data_x, data_y in data_loader:
-                loss = self.loss(data_x, data_y, n=len(data_loader.dataset), ignore_kl=ignore_kl)
+                if graphed is not None:
+                    # the whole step -- loss, backward, optimizer.step(), scheduler.step() -- as one hipGraph replay;
+                    # captured on the first batch, batches of another shape (a ragged last one) take the eager step
+                    if graphed.get("step") is None:
+                        from whvi_amd.graphs import GraphedTrainStep
+                        kept = getattr(self, "_train_graph", None)       # a later train_model call continues on the same graph
+                        options = graphed.get("options", {})
+                        if (kept is not None and kept.optimizer is optimizer and kept.scheduler is scheduler and kept.n == n
+                                and kept.ignore_kl == bool(ignore_kl) and kept.matches(data_x, data_y)
+                                and bool(options.get("static_eps", False)) == bool(kept.eps_buffers)):
+                            kept.restore_static_eps()
+                            graphed["step"] = kept
+                        else:
+                            graphed["step"] = self._train_graph = GraphedTrainStep(
+                                self, optimizer, data_x, data_y, n, ignore_kl=ignore_kl, scheduler=scheduler, **options)
+                    step = graphed["step"]
+                    if step.matches(data_x, data_y):
+                        hook = graphed.get("before_replay")
+                        if hook is not None:
+                            hook(step)
+                        step(data_x, data_y)
+                        continue
+                    # eager step beside a captured one: .grad still names the graph's static buffers -- detach from them
+                    # first, or this backward would accumulate into what the last replay left there
+                    self.zero_grad(set_to_none=True)
+                loss = self.loss(data_x, data_y, n=n, ignore_kl=ignore_kl)
                 loss.backward()
+                del loss                      # no graph of this pass may outlive it (GraphedTrainStep's precondition)
                 optimizer.step()
                 scheduler.step()
-                self.zero_grad(set_to_none=set_to_none)
+                self.zero_grad(set_to_none=set_to_none if graphed is None else True)
             if checkpoint_dir is not None and epoch % 5000 == 0:
                 torch.save(self.state_dict(), pathlib.Path(checkpoint_dir) / f'epoch-{epoch}.pth')
             if epoch % pbar_update_period == 0:
                 bar.set_description(f'[{label}] KL = {self.current_kl:.2f}, MNLL = {self.current_mnll:.2f}')
 
     def train_model(self, data_loader, optimizer, scheduler, epochs1: int = 500, epochs2: int = 5000,
-                    pbar_update_period=20, ignore_kl=False, checkpoint_dir=None):
+                    pbar_update_period=20, ignore_kl=False, checkpoint_dir=None, graphed=False, packed=None,
+                    graph_options=None):
         """Two phases as in src/networks.py:71-99.  As in the reference, the ``requires_grad``
         assignments below set a plain attribute on the likelihood MODULE and do not freeze its
-        ``sigma`` parameter -- kept so that training trajectories agree."""
+        ``sigma`` parameter -- kept so that training trajectories agree.
+
+        ``graphed=True`` (GPU; not in the reference) runs the SAME recipe -- the two phases, ``scheduler.step()`` after
+        every batch, the checkpoint cadence, the reference's ``state_dict`` keys -- with every step a hipGraph replay
+        (``whvi_amd.graphs.GraphedTrainStep``).  It needs an optimizer and a schedule whose state lives on the device:
+        ``make_optimizer(net, capturable=True[, packed=True])``.  ``packed=True`` additionally insists that the stacked
+        layers use the packed parameter layout (it has to be chosen BEFORE the optimizer is created: the optimizer holds
+        the parameter tensors).  ``graph_options``: keyword arguments for ``GraphedTrainStep`` (``static_eps``, ``warmup``)
+        plus an optional ``before_replay(step)`` callable run ahead of every replay."""
+        if packed:
+            unpacked = [m for m in self.modules() if hasattr(m, "pack_parameters") and m is not self and not m._packed]
+            if unpacked:
+                raise RuntimeError("train_model(packed=True): call net.pack_parameters() -- or make_optimizer(net, packed=True) "
+                                   "-- BEFORE creating the optimizer; the optimizer holds the parameter tensors")
+        state = None
+        if graphed:
+            options = dict(graph_options or {})
+            state = {"step": None, "before_replay": options.pop("before_replay", None), "options": options}
         self.train()
         self.likelihood.requires_grad = False
         self._epochs(data_loader, optimizer, scheduler, epochs1, 'Fixed LH', ignore_kl, pbar_update_period,
-                     set_to_none=True)
+                     set_to_none=True, graphed=state)
         self.likelihood.requires_grad = True
         self._epochs(data_loader, optimizer, scheduler, epochs2, 'Optimized LH', ignore_kl, pbar_update_period,
-                     checkpoint_dir=checkpoint_dir)
+                     checkpoint_dir=checkpoint_dir, graphed=state)
+        if state is not None and state["step"] is not None:
+            state["step"].release_static_eps()
         self.eval()
+        return state["step"] if state is not None else None
 
     def eval_model(self, X_test, y_test, loss) -> Tuple[float, float]:
         """(test error, test MNLL) with ``eval_samples`` draws (src/networks.py:101-115)."""

@@ -229,7 +229,15 @@ def _draw_and_reparam(module, g_mu, g_rho, n_samples, lambda_):
         if state is None or state.device != g_mu.device:
             state = module._rng_state = _hip.new_rng_state(g_mu.device, seed=_fresh_philox_seed())
         return ReparamKLPhiloxFunction.apply(g_mu, g_rho, state, n_samples, lambda_)
-    eps = torch.randn(J, n_samples, D, device=g_mu.device)
+    static = getattr(module, "_eps_static", None)
+    if static is None:
+        eps = torch.randn(J, n_samples, D, device=g_mu.device)
+    else:
+        # GraphedTrainStep(static_eps=True): the layer's draws come from a static buffer the caller refills between
+        # replays (recorded trajectories through a captured step); allocated -- with a real draw -- on first use
+        if static is True or tuple(static.shape) != (J, n_samples, D) or static.device != g_mu.device:
+            static = module._eps_static = torch.randn(J, n_samples, D, device=g_mu.device)
+        eps = static
     return _reparam(g_mu, g_rho, eps, lambda_)
 
 
