@@ -673,6 +673,40 @@ def multi_gpu_extras(device, rank, world, small=False):
                       f"(batch, 1, {n_mc // world}) blocks per forward, fp32, eval"}
     else:
         out["whviregression_3_1024_1024_1_mc128_sharded"] = {"skipped": err or "another rank failed to build the network"}
+    # ---- config 4, one TRAINING step with the 128 MC samples sharded: local batched pass + backward, one all-reduce
+    # (sum) of the O(D) parameter gradients, Adam (whvi_amd.parallel.mc_sharded_loss)
+    opt, err = None, None
+    try:
+        if net is not None:
+            from whvi_amd.parallel import mc_sharded_loss
+            train_batch = 256 if gpu and not small else 16
+            net.train()
+            if gpu:
+                net.pack_parameters()           # 13 parameter tensors instead of 1033: the host side of Adam
+            opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+            xt = torch.randn(train_batch, 3, device=device)
+            yt = torch.sin(xt.sum(dim=1, keepdim=True))
+            counter = [0]
+    except Exception as e:                      # noqa: BLE001
+        err = repr(e)
+    if _all_ok(opt is not None, device):
+        def train_step():
+            counter[0] += 1
+            opt.zero_grad(set_to_none=True)
+            mc_sharded_loss(net, xt, yt, n=45730, n_samples=n_mc, base_seed=counter[0])
+            opt.step()
+        ms = _timed_all_ranks(train_step, 5, device)
+        flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+        lo, hi = flat.clone(), flat.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        out["whviregression_3_1024_1024_1_mc128_sharded_train_step"] = {
+            "ms": round(ms, 3), "mc_samples_per_gpu": n_mc // world, "values_finite": _finite(flat),
+            "parameters_bit_equal_across_ranks": bool(torch.equal(lo, hi)),
+            "config": f"batch {train_batch} x 3, {n_mc} MC samples sharded over {world} ranks, one all-reduce(sum) of "
+                      f"{flat.numel()} parameter gradients per step, Adam, fp32, with KL"}
+    else:
+        out["whviregression_3_1024_1024_1_mc128_sharded_train_step"] = {"skipped": err or "another rank failed"}
     return out
 
 

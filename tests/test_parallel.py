@@ -148,6 +148,90 @@ def test_world_size_2_gloo(tmp_path):
     assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
 
 
+def _train_worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import copy
+        import torch.nn as nn
+        from torch.utils.data import DataLoader, TensorDataset
+        from whvi_amd.evaluation import make_optimizer
+        from whvi_amd.layers import WHVILinear
+        from whvi_amd.networks import WHVIRegression
+        S = 5                                                 # ragged: 3 samples on rank 0, 2 on rank 1
+        torch.manual_seed(11)                                 # replicated parameters and data: same seed on every rank
+        net = WHVIRegression([WHVILinear(3, 8, lambda_=2.0), nn.ReLU(), WHVILinear(8, 8, lambda_=2.0), nn.ReLU(),
+                              WHVILinear(8, 1, lambda_=2.0)], train_samples=S)
+        x, y = torch.randn(12, 3), torch.randn(12, 1)
+        single = copy.deepcopy(net)                           # the single-process reference, stepped beside the job
+        opt = torch.optim.Adam(net.parameters(), lr=0.05)
+        opt1 = torch.optim.Adam(single.parameters(), lr=0.05)
+        for step in range(1, 4):
+            # ---- one sharded step: local samples, backward, ONE all-reduce of the gradients
+            opt.zero_grad(set_to_none=True)
+            total = parallel.mc_sharded_loss(net, x, y, n=120, n_samples=S, base_seed=step)
+            # ---- the same step in ONE process fed the union of both ranks' eps (rank r's draws come from the generator
+            # seeded with (step, r), in rank order), through the plain single-process loss of src/networks.py:56-69
+            draws = []
+            for r in range(world):
+                lo, hi = parallel.shard_bounds(S, r, world)
+                with torch.random.fork_rng(devices=[]):
+                    torch.manual_seed(parallel.sample_seed(step, r))
+                    for _ in range(hi - lo):
+                        out = single.sequential(x)
+                        draws.append(out.reshape(x.size(0), out.size(-1)))
+            pred = torch.stack(draws, dim=2)
+            assert pred.shape == (12, 1, S)
+            loss1 = single.likelihood.mnll_batch_estimate(y, pred, 120) + single.kl
+            opt1.zero_grad(set_to_none=True)
+            loss1.backward()
+            assert abs(float(total) - float(loss1)) <= 1e-6 * abs(float(loss1)), (step, float(total), float(loss1))
+            for (name, p), q in zip(net.named_parameters(), single.parameters()):
+                assert p.grad is not None and torch.allclose(p.grad, q.grad, rtol=1e-5, atol=1e-6 * float(q.grad.abs().max()) + 1e-12), (step, name)
+            opt.step()
+            opt1.step()
+            for (name, p), q in zip(net.named_parameters(), single.parameters()):
+                assert torch.allclose(p, q, rtol=0.0, atol=1e-6), (step, name)
+        # replicated parameters are BIT-equal across ranks after three steps
+        flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+        both = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(both, flat)
+        assert torch.equal(both[0], both[1])
+        # ---- train_model picks the sharded step up by itself inside a process group (rank 0 writes the checkpoint)
+        calls = []
+        real = parallel.all_reduce_grads
+        parallel.all_reduce_grads = lambda module, average=True: (calls.append(average), real(module, average))[1]
+        try:
+            loader = DataLoader(TensorDataset(x, y), batch_size=6)
+            optimizer, scheduler = make_optimizer(net, lambda0=0.05)
+            ckpt = os.path.join(tmp, f"ckpt{rank}")
+            os.makedirs(ckpt)
+            net.train_model(loader, optimizer, scheduler, epochs1=1, epochs2=1, checkpoint_dir=ckpt)
+        finally:
+            parallel.all_reduce_grads = real
+        assert calls == [False] * 4, calls                    # 2 epochs x 2 batches, gradients SUMMED
+        assert (os.listdir(ckpt) == ["epoch-0.pth"]) == (rank == 0)
+        flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+        both = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(both, flat)
+        assert torch.equal(both[0], both[1])
+        with pytest.raises(RuntimeError, match="cannot be combined"):
+            net.train_model(loader, optimizer, scheduler, epochs1=0, epochs2=0, graphed=True)
+        open(os.path.join(tmp, f"train_ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_training_step_world_size_2_gloo(tmp_path):
+    """``parallel.mc_sharded_loss`` -- MC samples of a TRAINING step sharded over two ranks, one
+    all-reduce (sum) of the parameter gradients.  Loss, gradients and the parameters after each of three Adam steps
+    equal (1e-6) a single-process step over the union of both ranks' samples; the replicated parameters are bit-equal
+    across ranks; ``train_model`` uses the sharded step inside a process group."""
+    port = _free_port()
+    mp.spawn(_train_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "train_ok0").exists() and (tmp_path / "train_ok1").exists()
+
+
 def test_bench_two_ranks_gloo_cpu_plumbing(tmp_path):
     """bench.py's N > 1 control flow (barrier, max-over-ranks, single JSON line) on 2 CPU ranks."""
     import json

@@ -89,6 +89,45 @@ def test_mc_sharded_forward_and_grad_all_reduce(rccl_group):
             assert torch.equal(p.grad, g)                 # average over one rank
 
 
+def test_sharded_training_step_through_rccl(rccl_group, monkeypatch):
+    """``parallel.mc_sharded_loss`` on the GPU inside a one-rank RCCL group: the batched pass through the HIP kernels,
+    backward, the flattened gradient all-reduce and the scalar loss all-reduce really go through ``nccl``; with one
+    rank the step must equal the plain single-process loss with the same seeding, bit for bit; ``train_model`` takes
+    the sharded step by itself inside a group."""
+    from torch.utils.data import DataLoader, TensorDataset
+    from whvi_amd.evaluation import make_optimizer
+    dev = rccl_group
+    torch.manual_seed(6)
+    net = WHVIRegression([WHVILinear(3, 16, lambda_=2.0), nn.ReLU(), WHVILinear(16, 16, lambda_=2.0), nn.ReLU(),
+                          WHVILinear(16, 1, lambda_=2.0)], train_samples=4).to(dev).train()
+    x, y = torch.randn(10, 3, device=dev), torch.randn(10, 1, device=dev)
+    seen = []
+    real = dist.all_reduce
+    monkeypatch.setattr(dist, "all_reduce", lambda t, *a, **k: (seen.append((tuple(t.shape), t.device.type)), real(t, *a, **k))[1])
+    total = parallel.mc_sharded_loss(net, x, y, n=100, n_samples=4, base_seed=3)
+    n_params = sum(p.numel() for p in net.parameters())
+    assert seen == [((n_params,), "cuda"), ((), "cuda")], seen          # gradients (one flat buffer), then the loss scalar
+    grads = [p.grad.clone() for p in net.parameters()]
+    net.zero_grad(set_to_none=True)
+    with torch.random.fork_rng(devices=[dev]):
+        torch.manual_seed(parallel.sample_seed(3, 0))
+        want = net.loss(x, y, n=100)
+        want.backward()
+    assert float(total) == float(want)
+    for p, g in zip(net.parameters(), grads):
+        assert torch.equal(p.grad, g)
+    del want
+    net.zero_grad(set_to_none=True)
+    seen.clear()
+    loader = DataLoader(TensorDataset(x, y), batch_size=5)
+    optimizer, scheduler = make_optimizer(net, lambda0=0.05)
+    before = [p.detach().clone() for p in net.parameters()]
+    net.train_model(loader, optimizer, scheduler, epochs1=1, epochs2=1)      # a process group exists: sharded by itself
+    assert len(seen) == 8 and all(dev_type == "cuda" for _, dev_type in seen)   # 4 steps x (gradients + loss)
+    assert any(not torch.equal(p.detach(), b) for p, b in zip(net.parameters(), before))
+    assert all(bool(torch.isfinite(p).all()) for p in net.parameters())
+
+
 def test_graph_survives_an_evaluation_pass_with_the_inkernel_rng(rccl_group):
     """``mc_sharded_forward`` used to REPLACE every layer's Philox state tensor; a hipGraph captured
     before it kept launching with the old tensor's address (freed by then).  Now the state is re-seeded in place and
@@ -128,3 +167,5 @@ def test_bench_multi_gpu_phases_small(rccl_group):
     assert f16["rows_total"] == 4096 and f16["ms"] > 0
     net = out["whviregression_3_1024_1024_1_mc128_sharded"]
     assert net["prediction_shape"] == [33, 1, 8] and net["ms"] > 0
+    train = out["whviregression_3_1024_1024_1_mc128_sharded_train_step"]
+    assert train["ms"] > 0 and train["values_finite"] and train["mc_samples_per_gpu"] == 8

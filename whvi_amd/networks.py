@@ -128,11 +128,22 @@ class WHVINetwork(nn.Module, WHVI):
         return mnll if ignore_kl else mnll + kl
 
     def _epochs(self, data_loader, optimizer, scheduler, epochs, label, ignore_kl, pbar_update_period,
-                checkpoint_dir=None, set_to_none=False, graphed=None):
+                checkpoint_dir=None, set_to_none=False, graphed=None, sharded=False):
         bar = _progress(range(epochs), f'[{label}] KL = {self.current_kl:.2f}, MNLL = {self.current_mnll:.2f}')
         n = len(data_loader.dataset)
         for epoch in bar:
             for data_x, data_y in data_loader:
+                if sharded:
+                    # MC samples sharded over the ranks of the process group: every rank runs the same batch for its
+                    # share of the samples, one all-reduce of the parameter gradients, identical steps everywhere
+                    from whvi_amd import parallel
+                    self._sharded_steps = getattr(self, "_sharded_steps", 0) + 1
+                    parallel.mc_sharded_loss(self, data_x, data_y, n, self.train_samples, base_seed=self._sharded_steps,
+                                             ignore_kl=ignore_kl)
+                    optimizer.step()
+                    scheduler.step()
+                    self.zero_grad(set_to_none=set_to_none)
+                    continue
                 if graphed is not None:
                     # the whole step -- loss, backward, optimizer.step(), scheduler.step() -- as one hipGraph replay;
                     # captured on the first batch, batches of another shape (a ragged last one) take the eager step
@@ -164,14 +175,19 @@ class WHVINetwork(nn.Module, WHVI):
                 optimizer.step()
                 scheduler.step()
                 self.zero_grad(set_to_none=set_to_none if graphed is None else True)
-            if checkpoint_dir is not None and epoch % 5000 == 0:
+            if checkpoint_dir is not None and epoch % 5000 == 0 and (not sharded or self._is_rank_zero()):
                 torch.save(self.state_dict(), pathlib.Path(checkpoint_dir) / f'epoch-{epoch}.pth')
             if epoch % pbar_update_period == 0:
                 bar.set_description(f'[{label}] KL = {self.current_kl:.2f}, MNLL = {self.current_mnll:.2f}')
 
+    @staticmethod
+    def _is_rank_zero():
+        import torch.distributed as dist
+        return not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
+
     def train_model(self, data_loader, optimizer, scheduler, epochs1: int = 500, epochs2: int = 5000,
                     pbar_update_period=20, ignore_kl=False, checkpoint_dir=None, graphed=False, packed=None,
-                    graph_options=None):
+                    graph_options=None, sharded=None):
         """Two phases as in src/networks.py:71-99.  As in the reference, the ``requires_grad``
         assignments below set a plain attribute on the likelihood MODULE and do not freeze its
         ``sigma`` parameter -- kept so that training trajectories agree.
@@ -182,7 +198,19 @@ class WHVINetwork(nn.Module, WHVI):
         ``make_optimizer(net, capturable=True[, packed=True])``.  ``packed=True`` additionally insists that the stacked
         layers use the packed parameter layout (it has to be chosen BEFORE the optimizer is created: the optimizer holds
         the parameter tensors).  ``graph_options``: keyword arguments for ``GraphedTrainStep`` (``static_eps``, ``warmup``)
-        plus an optional ``before_replay(step)`` callable run ahead of every replay."""
+        plus an optional ``before_replay(step)`` callable run ahead of every replay.
+
+        ``sharded`` (not in the reference, which is single-process): ``None`` = automatically when a ``torch.distributed``
+        process group is initialised, ``True`` / ``False`` to force.  The ``train_samples`` Monte-Carlo samples of every
+        step are then split over the ranks (``whvi_amd.parallel.mc_sharded_loss``): each rank runs the SAME batch --
+        feed every rank the same data -- for its share of the samples, gradients are summed in one all-reduce, and the
+        replicated parameters stay bit-equal across ranks.  Step k draws from generators seeded with (k, rank)."""
+        if sharded is None:
+            from whvi_amd import parallel
+            sharded = parallel._in_group()
+        if sharded and graphed:
+            raise RuntimeError("train_model: graphed=True and sharded=True cannot be combined (the gradient all-reduce is "
+                               "not part of the captured step)")
         if packed:
             unpacked = [m for m in self.modules() if hasattr(m, "pack_parameters") and m is not self and not m._packed]
             if unpacked:
@@ -195,10 +223,10 @@ class WHVINetwork(nn.Module, WHVI):
         self.train()
         self.likelihood.requires_grad = False
         self._epochs(data_loader, optimizer, scheduler, epochs1, 'Fixed LH', ignore_kl, pbar_update_period,
-                     set_to_none=True, graphed=state)
+                     set_to_none=True, graphed=state, sharded=sharded)
         self.likelihood.requires_grad = True
         self._epochs(data_loader, optimizer, scheduler, epochs2, 'Optimized LH', ignore_kl, pbar_update_period,
-                     checkpoint_dir=checkpoint_dir, graphed=state)
+                     checkpoint_dir=checkpoint_dir, graphed=state, sharded=sharded)
         if state is not None and state["step"] is not None:
             state["step"].release_static_eps()
         self.eval()

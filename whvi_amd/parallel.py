@@ -19,7 +19,7 @@ import torch
 import torch.distributed as dist
 
 __all__ = ["init_from_env", "shard_bounds", "fwht_row_shard", "gather_predictions",
-           "mc_sharded_forward", "all_reduce_grads", "sample_seed", "seed_inkernel_rng"]
+           "mc_sharded_forward", "mc_sharded_loss", "all_reduce_grads", "sample_seed", "seed_inkernel_rng"]
 
 
 def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, torch.device]:
@@ -184,6 +184,81 @@ def mc_sharded_forward(net, x: torch.Tensor, n_samples: int, base_seed: int = 0)
                 draws.append(out.reshape(x.size(0), out.size(-1)))
             local = torch.stack(draws, dim=2)
     return gather_predictions(local, counts)
+
+
+def _local_predictions(net, x: torch.Tensor, n_local: int) -> torch.Tensor:
+    """``(batch, n_out, n_local)`` predictions of this rank's Monte-Carlo samples, with autograd."""
+    if n_local == 0:
+        n_out = net.sequential(x).size(-1)
+        return torch.zeros(x.size(0), n_out, 0, dtype=x.dtype, device=x.device)
+    mode = getattr(net, "mc_mode", "auto")
+    if mode == "auto":
+        mode = "batched" if x.device.type == "cuda" else "loop"
+    if mode == "batched" and hasattr(net, "forward_batched"):
+        return net.forward_batched(x, n_local)               # all local samples in one batched pass
+    draws = []
+    for _ in range(n_local):
+        out = net.sequential(x)
+        draws.append(out.reshape(x.size(0), out.size(-1)))
+    return torch.stack(draws, dim=2)
+
+
+def mc_sharded_loss(net, x: torch.Tensor, y: torch.Tensor, n: int, n_samples: int, base_seed: int = None,
+                    ignore_kl: bool = False, backward: bool = True) -> torch.Tensor:
+    """One training step's negative ELBO with the Monte-Carlo samples sharded over the ranks ("training
+    would add an all-reduce(sum) of 4.D-float gradient vectors per layer + likelihood.sigma").
+
+    The single-process loss of src/networks.py:56-69 with S samples is ``MNLL_S + KL`` where the MNLL estimate averages
+    over all S samples (src/likelihoods.py:26-28).  Rank r runs the FULL batch through the network for its S_r samples
+    and forms
+
+        loss_r = (S_r / S) . MNLL_{S_r}  +  KL / world
+
+    whose sum over ranks is exactly the single-process loss over the union of the ranks' samples; ``backward()`` then
+    yields each rank's share of the gradient and ONE flattened all-reduce (sum) of the O(D) parameter gradients makes
+    every rank hold the full gradient -- so identical optimizer steps keep the replicated parameters bit-equal across
+    ranks.  No collective on the data path.
+
+    ``x`` / ``y`` are the same batch on every rank.  ``base_seed``: when given, rank r draws from generators seeded
+    with (base_seed, r) for this call (reproducible; pass the step index); otherwise the current generators are used
+    (seed them per rank once).  Returns the detached global loss (one scalar all-reduce, for monitoring); with
+    ``backward=False`` only the local share is built and returned with its graph."""
+    import contextlib
+    rank, world = _world()
+    begin, end = shard_bounds(n_samples, rank, world)
+    n_local = end - begin
+    if base_seed is None:
+        context = contextlib.nullcontext()
+    else:
+        devices = [x.device] if x.device.type == "cuda" else []
+        context = contextlib.ExitStack()
+        context.enter_context(torch.random.fork_rng(devices=devices))
+        context.enter_context(_ForkedInkernelRng(net))
+    with context:
+        if base_seed is not None:
+            torch.manual_seed(sample_seed(base_seed, rank))
+            seed_inkernel_rng(net, base_seed, rank)
+        net._pass_kl = None
+        pred = _local_predictions(net, x, n_local)
+        mnll = net.likelihood.mnll_batch_estimate(y, pred, n) if n_local > 0 else pred.sum() * 0.0
+        pass_kl, net._pass_kl = getattr(net, "_pass_kl", None), None
+        local = mnll * (n_local / float(n_samples))
+        kl = None
+        if not ignore_kl:
+            kl = pass_kl if pass_kl is not None else net.kl
+            local = local + kl / world
+    net.current_mnll = mnll.detach() if torch.is_tensor(mnll) else mnll       # this rank's estimate (monitoring)
+    if kl is not None:
+        net.current_kl = kl.detach() if torch.is_tensor(kl) else kl
+    if not backward:
+        return local
+    local.backward()
+    total = local.detach().clone()
+    del local, mnll, pred                                    # no graph of this pass outlives it
+    all_reduce_grads(net, average=False)
+    if _in_group():
+        dist.all_reduce(total, op=dist.ReduceOp.SUM)
+    return total
 
 
 def all_reduce_grads(module: torch.nn.Module, average: bool = True) -> None:
