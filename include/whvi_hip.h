@@ -198,6 +198,19 @@ int whvi_wbar_fwd_f64(void *dst, const void *s1, const void *u, const void *s2, 
                       int64_t J, int64_t S, int64_t R, int32_t log2d, int64_t u_group, int64_t u_first,
                       void *stream);
 
+/* `w_bar(g_mu) + w_bar(g_sigma * eps_k)` of src/weights.py:93 in ONE launch: u is (J, 1 + S, D) -- row 0 of each group the
+ * mean vector, rows 1 .. S the samples (the buffer whvi_reparam_kl writes) -- and
+ *     dst[j,k,i,:] = s1[j,i] * fwht(u[j,0,i] * fwht(s2[j,i] e_i))  +  s1[j,i] * fwht(u[j,1+k,i] * fwht(s2[j,i] e_i)),
+ * both terms computed by the same wave (two in-register transforms per tile, no mean matrix in memory).  The same
+ * multiplies, butterflies and final add as whvi_wbar_fwd twice (mean matrix, then samples with `base`): the same bits.
+ * Meant for cache-resident results (a launch and the re-read of the mean matrix saved); streams keep the two-launch
+ * form, which does half the arithmetic per byte written.   dst : (J, S, R, D); log2d in [2, 12] (f32) / [1, 11] (f64):
+ * two 64-register tiles per wave -- longer rows return WHVI_ERR_SIZE (use whvi_wbar_fwd with `base`). */
+int whvi_wbar_fwd_mean_f32(void *dst, const void *s1, const void *u, const void *s2, int64_t J, int64_t S, int64_t R,
+                           int32_t log2d, void *stream);
+int whvi_wbar_fwd_mean_f64(void *dst, const void *s1, const void *u, const void *s2, int64_t J, int64_t S, int64_t R,
+                           int32_t log2d, void *stream);
+
 /* Backward of the weight construction in ONE launch: reads the incoming gradient once, writes three scalars per
  * row.  The reference obtains the same quantities from autograd over its op chain (matmul_diag_left backward,
  * src/utils.py:4-12, and FWHTFunction.backward = FWHT, src/fwht/cuda/fwht.py:14-16): four more FWHT launches and

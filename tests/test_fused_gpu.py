@@ -922,3 +922,29 @@ def test_network_and_likelihood_vs_reference_on_gpu(monkeypatch, hip_lib):
     target *= n / m
     got = float(GaussianLikelihood(sigma=sigma).to(DEV).mnll_batch_estimate(y.to(DEV), y_hat.to(DEV), n))
     assert abs(target - got) < 1e-4 * max(1.0, abs(target))
+
+
+@pytest.mark.parametrize("dtype,J,S,D,R", [(torch.float32, 1, 32, 512, 512), (torch.float32, 256, 16, 4, 4), (torch.float32, 1, 3, 1024, 1024),
+                                           (torch.float32, 1, 2, 4096, 4096), (torch.float32, 3, 2, 64, 5), (torch.float64, 2, 3, 256, 256),
+                                           (torch.float64, 1, 2, 2048, 7), (torch.float32, 1, 5, 8, 1)])
+def test_one_launch_mean_plus_sample_weights_equal_the_two_launch_form(dtype, J, S, D, R, hip_lib):
+    """``whvi_wbar_fwd_mean`` (both terms of ``w_bar(g_mu) + w_bar(g_sigma eps_k)``, src/weights.py:93, by the same wave)
+    against the two-launch form (mean matrix, then samples with the mean added in the epilogue) and, through it, the
+    oracle-pinned generic fused launch: bit for bit, BASELINE config 2's and config 4's layer shapes included; rows of
+    one 128-register tile keep the two-launch form."""
+    g = torch.Generator().manual_seed(D + S)
+    s1, s2 = (torch.randn(J, D, generator=g, dtype=dtype).to(DEV) for _ in range(2))
+    u = torch.randn(J, 1 + S, D, generator=g, dtype=dtype).to(DEV)
+    one = _hip.wbar_fwd_mean(s1, u, s2, R, inline=True)
+    assert _hip.last_kernel().endswith(", false, true>"), _hip.last_kernel()
+    two = _hip.wbar_fwd_mean(s1, u, s2, R, inline=False)
+    assert not _hip.last_kernel().endswith(", true, true>") and one.shape == (J, S, R, D)
+    assert torch.equal(one.view(torch.uint8), two.view(torch.uint8))
+    every = _hip.wbar_fwd(s1, u, s2, R)                                        # (J, 1 + S, R, D): the terms on their own
+    assert torch.equal(one, every[:, :1] + every[:, 1:])
+    W = WBarFunction.apply(s1, u, s2, None if R == D else R, True)             # what the layers call: picks by size
+    assert torch.equal(W, one)
+    long_d = 8192 if dtype == torch.float32 else 4096
+    with pytest.raises(RuntimeError, match="two-launch form only"):
+        _hip.wbar_fwd_mean(torch.zeros(1, long_d, dtype=dtype, device=DEV), torch.zeros(1, 2, long_d, dtype=dtype, device=DEV),
+                           torch.zeros(1, long_d, dtype=dtype, device=DEV), 1, inline=True)

@@ -84,6 +84,9 @@ def _declare_f3(lib):
         fn = getattr(lib, "whvi_wbar_fwd_" + sfx)
         fn.restype = ctypes.c_int
         fn.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, ctypes.c_int32, i64, i64, vp]
+        fn = getattr(lib, "whvi_wbar_fwd_mean_" + sfx)
+        fn.restype = ctypes.c_int
+        fn.argtypes = [vp, vp, vp, vp, i64, i64, i64, ctypes.c_int32, vp]
 
 
 def lib():
@@ -343,6 +346,41 @@ def wbar_fwd(s1: torch.Tensor, u: torch.Tensor, s2: torch.Tensor, rows: int = No
         rc = fn(out.data_ptr(), s1.data_ptr(), u.data_ptr(), s2.data_ptr(), None if base is None else base.data_ptr(),
                 J, S, R, D.bit_length() - 1, G, int(first), _stream(u))
     _check(rc, "whvi_wbar_fwd")
+    return out
+
+
+# results up to this size take the one-launch mean + sample form (whvi_wbar_fwd_mean); beyond it the two-launch form wins
+# (half the arithmetic per byte written once the write stream itself is the bound).  Measured, interleaved, HIP events
+# (tools/probe_wbar_mean.py, profiles/r03/wbar_mean_one_vs_two_launches.log): 256 matrices of D = 4 x 16 samples 7.5 vs
+# 16.3 us, D = 512 x 32 (32 MiB, config 2) 12.9 vs 16.8 us; D = 1024 x 16 (64 MiB) 21.1 vs 17.1, 128 MiB 35 vs 25
+WBAR_INLINE_MEAN_MAX_BYTES = 48 << 20
+
+
+def wbar_fwd_mean(s1: torch.Tensor, u: torch.Tensor, s2: torch.Tensor, rows: int = None, inline: bool = None):
+    """W (J, S, R, D) with W[j,k] = w_bar(u[j,0]) + w_bar(u[j,1+k]) for u (J, 1 + S, D) -- src/weights.py:93.  One launch
+    computing both terms (``whvi_wbar_fwd_mean``) for cache-resident results, otherwise the mean matrix once and every
+    sample's matrix with the mean added in its epilogue (two launches of ``whvi_wbar_fwd``).  Same bits either way;
+    ``inline`` forces the choice (tests, A/B)."""
+    if u.device.type != "cuda" or u.dtype not in (torch.float32, torch.float64):
+        raise RuntimeError("wbar_fwd_mean: float32 / float64 CUDA tensors only")
+    J, G, D = u.shape
+    S, R = G - 1, (D if rows is None else int(rows))
+    if S < 0 or tuple(s1.shape) != (J, D) or tuple(s2.shape) != (J, D) or not (s1.dtype == s2.dtype == u.dtype):
+        raise RuntimeError("wbar_fwd_mean: operands do not match u")
+    fits = D <= (4096 if u.dtype == torch.float32 else 2048)      # two 64-register tiles per wave
+    if inline is None:
+        inline = fits and J * S * R * D * u.element_size() <= WBAR_INLINE_MEAN_MAX_BYTES
+    elif inline and not fits:
+        raise RuntimeError("wbar_fwd_mean: rows this long have the two-launch form only")
+    if not inline:
+        mean = wbar_fwd(s1, u, s2, R, first=0, count=1)                        # (J, 1, R, D): w_bar(g_mu), once
+        return wbar_fwd(s1, u, s2, R, base=mean.view(J, R, D), first=1)        # + w_bar(g_sigma * eps_k), per sample
+    s1, u, s2 = s1.contiguous(), u.contiguous(), s2.contiguous()
+    out = torch.empty((J, S, R, D), dtype=u.dtype, device=u.device)
+    fn = getattr(lib(), "whvi_wbar_fwd_mean_" + _DTYPE_SUFFIX[u.dtype])
+    with _OnDevice(u.device):
+        rc = fn(out.data_ptr(), s1.data_ptr(), u.data_ptr(), s2.data_ptr(), J, S, R, D.bit_length() - 1, _stream(u))
+    _check(rc, "whvi_wbar_fwd_mean")
     return out
 
 

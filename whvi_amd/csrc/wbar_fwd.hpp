@@ -16,7 +16,10 @@ namespace whvi {
 // rows are (J, S, R) x D; s1 / s2 are (J, D); matrix (j, k) reads row j * u_group + u_first + k of u (so a
 // (J, 1 + S, D) buffer serves both the mean call -- u_first = 0, S = 1 -- and the per-sample call -- u_first = 1);
 // base is (J, R, D) or null
-template <typename T, int LOG2D, int K, bool NT>
+// INLINE_MEAN (round 3, cache-resident sizes): W[j,k] = w_bar(u[j,0]) + w_bar(u[j,1+k]) with the MEAN term computed by the
+// same wave -- one more in-register transform per tile -- instead of being built by a launch of its own and re-read by
+// every sample.  Same multiplies, same butterflies, same final add (mean + sample) as the two-launch form: same bits.
+template <typename T, int LOG2D, int K, bool NT, bool INLINE_MEAN = false>
 __global__ void __launch_bounds__(256)
 wbar_fwd_kernel(u32x4 *dst, const T *s1, const T *u, const T *s2, const u32x4 *base, int64_t n_chunks,
                 int64_t n_tiles, uint32_t n_rows, FastDiv by_r, FastDiv by_s, uint32_t u_group, uint32_t u_first,
@@ -65,6 +68,7 @@ wbar_fwd_kernel(u32x4 *dst, const T *s1, const T *u, const T *s2, const u32x4 *b
     auto chunk_col = [&](int k) -> uint32_t { return (uint32_t)(k * 64 + lane) & (CPR - 1); };
 
     A r[K][VEC];
+    A mean[INLINE_MEAN ? K : 1][VEC];
     A s1v[K];
     uint32_t base_row[K];
 #pragma unroll
@@ -74,19 +78,36 @@ wbar_fwd_kernel(u32x4 *dst, const T *s1, const T *u, const T *s2, const u32x4 *b
         const uint32_t i = row - jk * by_r.d;
         const uint32_t j = by_s.div(jk);
         const uint32_t urow = j * u_group + u_first + (jk - j * by_s.d);
-        const A v = (A)u[(size_t)urow * D + i] * (A)s2[(size_t)j * D + i];
+        const A s2v = (A)s2[(size_t)j * D + i];
+        const A v = (A)u[(size_t)urow * D + i] * s2v;
         s1v[k] = (A)s1[(size_t)j * D + i];
         base_row[k] = j * by_r.d + i;
         // H[i,d] = (-1)^popcount(i & d), d = d0 + e with d0 a multiple of VEC: one parity per chunk, one per position
         const bool par_k = __builtin_popcount(i & (chunk_col(k) * VEC)) & 1;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) r[k][e] = (par_k != (bool)(__builtin_popcount(i & (uint32_t)e) & 1)) ? -v : v;
+        if constexpr (INLINE_MEAN) {
+            const A v0 = (A)u[(size_t)(j * u_group) * D + i] * s2v;       // row 0 of the group: the mean vector
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) mean[k][e] = (par_k != (bool)(__builtin_popcount(i & (uint32_t)e) & 1)) ? -v0 : v0;
+        }
+    }
+    if constexpr (INLINE_MEAN) {
+        fwht_tile<A, VEC, K, LOG2D, POLICY_DPP, 0>(mean, lane);
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) mean[k][e] = s1v[k] * mean[k][e];
     }
     fwht_tile<A, VEC, K, LOG2D, POLICY_DPP, 0>(r, lane);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
 #pragma unroll
         for (int e = 0; e < VEC; ++e) r[k][e] = s1v[k] * r[k][e];
+        if constexpr (INLINE_MEAN) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) r[k][e] = mean[k][e] + r[k][e];
+        }
         if (base != nullptr) {
             A m[VEC];
             E::unpack(base[(size_t)base_row[k] * CPR + chunk_col(k)], m);
@@ -107,7 +128,7 @@ wbar_fwd_kernel(u32x4 *dst, const T *s1, const T *u, const T *s2, const u32x4 *b
 
 template <typename T, int LOG2D>
 inline void launch_wbar_fwd(void *dst, const void *s1, const void *u, const void *s2, const void *base, int64_t rows,
-                            int64_t S, int64_t R, int64_t u_group, int64_t u_first, hipStream_t st)
+                            int64_t S, int64_t R, int64_t u_group, int64_t u_first, bool inline_mean, hipStream_t st)
 {
     constexpr int K = pick_k<T, LOG2D>();
     constexpr int VEC = Elem<T>::VEC;
@@ -121,6 +142,19 @@ inline void launch_wbar_fwd(void *dst, const void *s1, const void *u, const void
     constexpr int LVc = ilog2(VEC);
     constexpr int NEED = (LOG2D > LVc + 6) ? (1 << (LOG2D - LVc - 6)) : 1;
     constexpr int KS = NEED > 4 ? NEED : 4;
+    if (inline_mean) {
+        // the mean term computed in the same launch (whvi_wbar_fwd_mean_*): quarter-size tiles, cached stores.  Two tiles
+        // live at once: rows of one 128-register tile (f32 D = 8192, f64 D = 4096) are refused by the dispatch
+        constexpr int KM = KS < K ? KS : K;
+        if constexpr (tile_vgprs<T, KM>() <= 64) {
+            const int64_t tiles_m = (n_chunks + 64 * KM - 1) / (64 * KM);
+            note_launch<T>("wbar_fwd_kernel", LOG2D, KM, false, true);
+            hipLaunchKernelGGL((wbar_fwd_kernel<T, LOG2D, KM, false, true>), dim3((unsigned)((tiles_m + 3) / 4)), dim3(256), 0, st,
+                               (u32x4 *)dst, (const T *)s1, (const T *)u, (const T *)s2, (const u32x4 *)nullptr, n_chunks, tiles_m,
+                               (uint32_t)rows, dr, ds, (uint32_t)u_group, (uint32_t)u_first, 0u, 0u);
+        }
+        return;
+    }
     // blocks per matrix / 8 when the XCD-sliced order applies (see the kernel): a mean matrix is added, every matrix
     // is a whole number of 8 x 4-tile groups, and the grid is exactly the matrices' blocks
     static const bool xcd_off = [] { const char *e = WHVI_TUNE_ENV("WHVI_WBAR_FWD_XCD"); return e != nullptr && e[0] == '0'; }();   // A/B switch (tuning builds)
@@ -169,7 +203,8 @@ inline void launch_wbar_fwd(void *dst, const void *s1, const void *u, const void
 
 template <typename T>
 inline int wbar_fwd_dispatch(void *dst, const void *s1, const void *u, const void *s2, const void *base, int64_t J,
-                             int64_t S, int64_t R, int32_t log2d, int64_t u_group, int64_t u_first, void *stream)
+                             int64_t S, int64_t R, int32_t log2d, int64_t u_group, int64_t u_first, void *stream,
+                             bool inline_mean = false)
 {
     constexpr int LV = ilog2(Elem<T>::VEC);
     g_err[0] = 0;
@@ -177,6 +212,9 @@ inline int wbar_fwd_dispatch(void *dst, const void *s1, const void *u, const voi
     if (log2d < LV || log2d > max_single_pass_log2d<T>())
         return fail(WHVI_ERR_SIZE, "whvi_wbar_fwd: log2(D)%s = %lld is outside the supported range [%lld, ...]", "",
                     log2d, LV);
+    if (inline_mean && log2d > multi_pass_low_log2d<T>())
+        return fail(WHVI_ERR_SIZE, "whvi_wbar_fwd_mean: log2(D)%s = %lld is beyond the one-launch form (two 64-register tiles); "
+                    "build the mean matrix with whvi_wbar_fwd and pass it as `base`", "", log2d);
     if (R > ((int64_t)1 << log2d)) return fail(WHVI_ERR_ARG, "whvi_wbar_fwd: R%s = %lld exceeds D", "", R);
     if (u_first < 0 || u_group < u_first + S || u_group >= ((int64_t)1 << 31))
         return fail(WHVI_ERR_ARG, "whvi_wbar_fwd: u_group%s = %lld does not hold rows u_first .. u_first + S", "", u_group);
@@ -190,7 +228,7 @@ inline int wbar_fwd_dispatch(void *dst, const void *s1, const void *u, const voi
 #define WHVI_CASE(L)                                                                                       \
     case L:                                                                                                \
         if constexpr (L >= LV && L <= max_single_pass_log2d<T>())                                          \
-            launch_wbar_fwd<T, L>(dst, s1, u, s2, base, rows, S, R, u_group, u_first, st);                                    \
+            launch_wbar_fwd<T, L>(dst, s1, u, s2, base, rows, S, R, u_group, u_first, inline_mean, st);                       \
         break;
     switch (log2d) {
         WHVI_CASE(1) WHVI_CASE(2) WHVI_CASE(3) WHVI_CASE(4) WHVI_CASE(5) WHVI_CASE(6) WHVI_CASE(7)

@@ -61,8 +61,9 @@ class WBarFunction(torch.autograd.Function):
             # dedicated launch (whvi_wbar_fwd): one transform per row, no HBM read
             if not mean_plus:
                 return _hip.wbar_fwd(s1, u, s2, R)
-            mean = _hip.wbar_fwd(s1, u, s2, R, first=0, count=1)              # (J, 1, R, D): w_bar(g_mu), once
-            return _hip.wbar_fwd(s1, u, s2, R, base=mean.view(J, R, D), first=1)   # + w_bar(g_sigma * eps_k), per sample
+            # w_bar(g_mu) + w_bar(g_sigma * eps_k): one launch computing both terms while the result is cache-resident,
+            # the mean matrix once + every sample with the mean added in its epilogue beyond (same bits)
+            return _hip.wbar_fwd_mean(s1, u, s2, R)
         # rows shorter than one 16-byte chunk (D = 1, 2): the generic fused launch with the identity input.  Rows
         # of each (j, k) matrix form one group of R rows; with several matrices every group carries its own s1 / s2
         if J == 1:
