@@ -293,7 +293,8 @@ def cpu_baseline(log2d, target_s=25.0):
 def _rate(rows, d, elem_bytes, ms):
     gbs = rows * 2 * d * elem_bytes / (ms * 1e-3) / 1e9
     return {"rows": rows, "ms": round(ms, 4), "Gtransforms_per_s": round(rows / (ms * 1e-3) / 1e9, 4),
-            "GB_per_s": round(gbs, 1), "frac_of_peak": round(gbs / HBM_PEAK_GBS, 4)}
+            "GB_per_s": round(gbs, 1), "frac_of_peak": round(gbs / HBM_PEAK_GBS, 4),
+            "algorithmic_bytes_per_launch": rows * 2 * d * elem_bytes}
 
 
 def _extra_sweep(device):
@@ -340,7 +341,17 @@ def _extra_f16(device):
     # switching power, higher clock) -- round 1's 6.39 TB/s was measured on data that had overflowed.
     res = _rate(1 << 20, 4096, 2, event_ms_each(lambda: _hip.fwht_rows(x, out=x), lambda i: x.mul_(2.0 ** -6), iters=12, warm=12))
     res.update(kernel=_hip.last_kernel(), values_finite=_finite(x))
+    _attach_traffic(res, "fwht_f16_D4096_rows1048576")
     return res
+
+
+def _attach_traffic(res, workload_key):
+    """``traffic`` (HBM bytes per launch from the PMC passes under profiles/, FETCH_SIZE doubled + WRITE_SIZE) for an extras
+    entry, under the headline's rule: only when the record's kernel symbol AND kernel-source hash are this build's."""
+    value, note = recorded_traffic(workload_key, res.get("kernel"))
+    res["traffic"], res["traffic_note"] = value, note
+    if value is not None and res.get("algorithmic_bytes_per_launch"):
+        res["traffic_over_algorithmic"] = round(value / res["algorithmic_bytes_per_launch"], 5)
 
 
 def _extra_fused(device):
@@ -358,6 +369,7 @@ def _extra_fused(device):
     res.update(kernel=_hip.last_kernel(), values_finite=_finite(x), max_abs_after_50_launches=float(x[::4099].abs().max()))
     res["note"] = ("one fused launch = 2 FWHTs + 3 scalings per row; unfused (2 FWHT launches + 3 elementwise) "
                    "moves 5x the bytes")
+    _attach_traffic(res, "fused_shs_f32_D2048_S64_B8192")
     return res
 
 

@@ -4,7 +4,8 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import _tuning  # noqa: E402  (tools/_tuning.py: the environment switches exist in measurement builds only)
-_tuning.use()
+if os.environ.get("WHVI_STREAM_BIG_BLOCKS"):      # an environment switch is set: it exists in the measurement build only
+    _tuning.use()
 import torch
 from whvi_amd import _hip
 tag = "big-blocks" if os.environ.get("WHVI_STREAM_BIG_BLOCKS") else "256+barrier"

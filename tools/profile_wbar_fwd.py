@@ -5,7 +5,8 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import _tuning  # noqa: E402  (tools/_tuning.py: the environment switches exist in measurement builds only)
-_tuning.use()
+if os.environ.get("WHVI_WBAR_FWD_TILES") or os.environ.get("WHVI_WBAR_FWD_XCD"):      # an environment switch is set: it exists in the measurement build only
+    _tuning.use()
 import torch
 from whvi_amd import _hip
 
@@ -20,6 +21,10 @@ for (J, S, D) in shapes:
         out = _hip.wbar_fwd(s1, u, s2, D, base=base, first=1)
     torch.cuda.synchronize()
     print(J, S, D, _hip.last_kernel(), bool(torch.isfinite(out).all()), flush=True)
+    for _ in range(25):                                     # what WHVILinear.forward_mc calls: one or two launches by size
+        out = _hip.wbar_fwd_mean(s1, u, s2, D)
+    torch.cuda.synchronize()
+    print(J, S, D, "production mean + samples:", _hip.last_kernel(), flush=True)
     u2 = u[:, 1:].contiguous()
     for _ in range(25):                                     # without the mean matrix (direct sampling): a pure write stream
         out = _hip.wbar_fwd(s1, u2, s2, D)

@@ -5,7 +5,8 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import _tuning  # noqa: E402  (tools/_tuning.py: the environment switches exist in measurement builds only)
-_tuning.use()
+if os.environ.get("WHVI_FUSED_TUNE"):      # an environment switch is set: it exists in the measurement build only
+    _tuning.use()
 import torch
 from whvi_amd import _hip
 

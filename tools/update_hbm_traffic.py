@@ -1,4 +1,4 @@
-"""tools/update_hbm_traffic.py KEY FETCH_DIR WRITE_DIR [KERNEL_SUBSTRING] -- turn two rocprofv3 --pmc passes
+"""tools/update_hbm_traffic.py KEY FETCH_DIR WRITE_DIR [KERNEL_SUBSTRING [ALGORITHMIC_BYTES]] -- turn two rocprofv3 --pmc passes
 (FETCH_SIZE, WRITE_SIZE; tools/pmc_cmd.sh) of `bench.py --no-extras --no-cpu-baseline` into the record bench.py reports
 as `roofline.traffic`: profiles/hbm_traffic.json[KEY], stamped with the kernel symbol and the hash of the kernel
 sources (bench.kernel_source_hash) so a later build cannot silently inherit it.
@@ -30,12 +30,16 @@ def main():
     needle = sys.argv[4] if len(sys.argv) > 4 else "fwht_rows_kernel<float, 12"
     fetch = counter_rows(fetch_dir, "FETCH_SIZE", needle)
     write = counter_rows(write_dir, "WRITE_SIZE", needle)
-    name = fetch[0]["Kernel_Name"]
+    # one instantiation only: the launches of the most frequent symbol (a script may end with a few launches of another form)
+    names = [r["Kernel_Name"] for r in fetch]
+    name = max(set(names), key=names.count)
+    fetch = [r for r in fetch if r["Kernel_Name"] == name]
+    write = [r for r in write if r["Kernel_Name"] == name]
     symbol = "whvi::" + re.search(r"whvi::(\w+<[^>]*>)", name).group(1)
     f_kib = sum(float(r["Counter_Value"]) for r in fetch) / len(fetch)
     w_kib = sum(float(r["Counter_Value"]) for r in write) / len(write)
     m = re.match(r"fwht_f32_D(\d+)_rows(\d+)", key)
-    alg = 2 * int(m.group(1)) * 4 * int(m.group(2)) if m else None
+    alg = int(sys.argv[5]) if len(sys.argv) > 5 else (2 * int(m.group(1)) * 4 * int(m.group(2)) if m else None)
     rec = {"hbm_bytes_per_launch": int(round((2 * f_kib + w_kib) * 1024)),
            "read_bytes_corrected": int(round(2 * f_kib * 1024)), "write_bytes": int(round(w_kib * 1024)),
            "FETCH_SIZE_raw_KB": f_kib, "WRITE_SIZE_raw_KB": w_kib, "launches_averaged": [len(fetch), len(write)],
