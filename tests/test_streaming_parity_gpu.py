@@ -32,7 +32,10 @@ def expected_fused_kernel(dtype, log2d, per_sample, layout):
     1 = a and c (shared ones, or those of the block's one sample), 0 = none (every vector from L2)."""
     name, esize = ("float", 4) if dtype == torch.float32 else ("double", 8)
     K = 32 if (dtype == torch.float64 and log2d == 12) else 16      # one f64 row of 4096 per wave: 128 data registers
-    stage = 1 if (layout == "sample" or not per_sample) else 0      # "sample": whole blocks inside one sample
+    # staged: shared a / c always; per-sample ones when whole blocks lie inside one sample -- rows in (sample, batch, D)
+    # order with an aligned batch, or (batch, sample, D) order with one 128-register row per tile (f64 D = 4096), where
+    # the block takes four rows of the same sample, S rows apart
+    stage = 1 if (not per_sample or layout == "sample" or (layout == "batch" and K == 32)) else 0
     return f"whvi::fused_shs_kernel<{name}, {log2d}, {K}, 1, false, true, 256, 0, {stage}>"
 
 

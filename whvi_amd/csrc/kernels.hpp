@@ -684,7 +684,7 @@ template <typename T, int LOG2D, int K, int AXIS, bool EYE, bool NT, int BLOCK, 
 __global__ void __launch_bounds__(BLOCK)
 fused_shs_kernel(u32x4 *dst, const u32x4 *src, const T *a, const T *b, const T *c,
                  int64_t n_chunks, int64_t n_tiles, FastDiv by_sample_stride, FastDiv by_n_samples,
-                 FastDiv by_group_rows, int flags)
+                 FastDiv by_group_rows, int flags, uint32_t same_sample_blocks)
 {
     const bool a_per_sample = flags & WHVI_FUSED_A_PER_SAMPLE;
     const bool c_per_sample = flags & WHVI_FUSED_C_PER_SAMPLE;
@@ -703,7 +703,16 @@ fused_shs_kernel(u32x4 *dst, const u32x4 *src, const T *a, const T *b, const T *
     // streams: XCD-contiguous block order and a block barrier before the stores, as in fwht_rows_kernel
     int64_t blk = blockIdx.x;
     if (NT && (gridDim.x & 7) == 0) blk = (blk & 7) * (int64_t)(gridDim.x >> 3) + (blk >> 3);
-    const int64_t t = blk * (BLOCK / 64) + wave;
+    int64_t t = blk * (BLOCK / 64) + wave;
+    // same_sample_blocks (host: rows in (batch, sample, D) order, one row per tile, whole groups of 4 x n_samples rows,
+    // per-sample a / c): the block's waves take rows s, s + S, s + 2 S, s + 3 S of one group -- ONE sample, so its a and c
+    // can be staged once per block like shared ones instead of three vectors per tile coming through L2 (where at 16 KiB
+    // per vector and 64 samples they no longer all stay: +14 % fabric reads, profiles/r03).  Consecutive blocks take
+    // consecutive s: a group of S blocks still covers 4 S contiguous rows.
+    if (same_sample_blocks != 0u) {
+        const uint32_t q = by_n_samples.div((uint32_t)blk), smp = (uint32_t)blk - q * by_n_samples.d;
+        t = ((int64_t)q * (BLOCK / 64) + wave) * by_n_samples.d + smp;
+    }
     const bool active = t < n_tiles;                          // wave-uniform; a block always has at least one active wave
     const int64_t base = t * TILE;
     const uint32_t row0 = (uint32_t)(base >> SH);             // first row of the tile (wave-uniform)
@@ -731,7 +740,8 @@ fused_shs_kernel(u32x4 *dst, const u32x4 *src, const T *a, const T *b, const T *
     A *const stg_dst[3] = {lds_c, lds_a, lds_b};
     if constexpr (STAGE != STAGE_NONE) {
         // the block's sample: read only where a vector is per-sample (all rows of the block then share it: host-checked)
-        const uint32_t blk_row0 = (uint32_t)((blk * (BLOCK / 64) * TILE) >> SH);
+        const int64_t t_first = same_sample_blocks != 0u ? t - (int64_t)wave * by_n_samples.d : blk * (BLOCK / 64);   // wave 0's tile
+        const uint32_t blk_row0 = (uint32_t)((t_first * TILE) >> SH);
         const size_t s_off = (size_t)sample_index(blk_row0) << LOG2D;
         stg_src[0] = c == nullptr ? nullptr : c + (c_per_sample ? s_off : 0);
         stg_src[1] = a == nullptr ? nullptr : a + (a_per_sample ? s_off : 0);
