@@ -488,9 +488,12 @@ def test_config5_full_size_16bit_fwht_vs_oracle(dtype, hip_lib):
 
 @pytest.mark.gpu
 def test_config4_full_size_share_vs_host_path(monkeypatch, hip_lib):
-    """BASELINE config 4 at one GPU's share of its timed size: the 3 -> 1024 -> 1024 -> 1 network, protein-sized batch
-    (45 730 rows), 16 of the 128 MC samples, batched predictive pass on the GPU.  64 sampled batch rows x all samples
-    against the host path (the reference's op chain) run on just those rows with the same parameters and eps; 1e-5."""
+    """Checked against THIS REPO'S HOST PATH, not against the oracle or a reference fixture: BASELINE config 4 at one GPU's
+    share of its timed size -- the 3 -> 1024 -> 1024 -> 1 network, protein-sized batch (45 730 rows), 16 of the 128 MC
+    samples, batched predictive pass on the GPU -- on 64 sampled batch rows x all samples against the host path (the
+    reference's op chain as torch ops) run on just those rows with the same parameters and eps, 1e-5.  What ties the host
+    path to the reference: its bundles recorded from the live reference (tests/test_host.py) and this very network against
+    the reference-recorded fixture at batch 6 (test_config4_network_vs_reference_{cpu,gpu})."""
     import copy
     S, B = 16, 45730
     g = _npz("config4_golden.npz")
