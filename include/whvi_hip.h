@@ -77,9 +77,10 @@ int         whvi_max_log2d(int32_t dtype);  /* largest supported log2(D): 24 for
  * Replaces fwht_cuda_frontend (fwht_cuda_kernel.cu:156-181) + the X.clone() of
  * fwht_cuda.cpp:11 (pass dst != src for the reference's out-of-place semantics).
  *
- * Sign of zero (f32 only; every other bit of every result, NaN positions included, is independent of the launch form):
- * the streaming launch of whvi_fwht_f32 for D = 512 .. 2048 (buffers beyond the 256 MiB Infinity Cache) and both fused
- * pipelines run their lane stages as fused multiply-adds by +/-1, through which a zero carries no sign.  A result that
+ * Sign of zero (f32 / f64; every other bit of every result, NaN positions included, is independent of the launch form):
+ * the streaming launches (buffers beyond the 256 MiB Infinity Cache) of whvi_fwht_f32 for D = 512 .. 2048 and of
+ * whvi_fwht_f64 for D = 64 .. 2048, and both fused pipelines, run their lane stages as fused multiply-adds by +/-1,
+ * through which a zero carries no sign.  A result that
  * is NEGATIVE zero in the reference's arithmetic (-0 + -0: element 0 of a row made of negative zeros only) may therefore
  * come back as +0 from those launches while the cache-resident launch of the same call returns -0; exact cancellations are +0
  * either way.  Callers that compare raw bits across batch sizes should compare zeros by value

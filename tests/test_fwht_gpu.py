@@ -461,28 +461,33 @@ def test_bench_line_on_the_gpu(hip_lib):
     assert rec["config"]["values_finite_after_run"] is True
 
 
-@pytest.mark.parametrize("log2d", [9, 10, 11])
-def test_signed_streaming_launch_of_f32_rows(log2d, hip_lib):
-    """f32 streams of D = 512 .. 2048 beyond the Infinity Cache take the SIGNED DPP network (one v_fmac_f32_dpp per
-    lane-stage element, the tile carrying (-1)^popcount(lane & 15) until one repair multiply at the end): 320 MiB in
-    place, random floats and small integers, sampled rows bit-identical to the oracle -- and to the unsigned network
-    (a cached out-of-place launch of the same rows) -- and H.H = D.I exactly on the integers."""
+@pytest.mark.parametrize("dtype,log2d", [(torch.float32, 9), (torch.float32, 10), (torch.float32, 11),
+                                         (torch.float64, 6), (torch.float64, 9), (torch.float64, 11)])
+def test_signed_streaming_launch_of_f32_and_f64_rows(dtype, log2d, hip_lib):
+    """f32 streams of D = 512 .. 2048 and f64 streams of D = 64 .. 2048 beyond the Infinity Cache take the SIGNED DPP
+    network (one fma per lane-stage element, the tile carrying (-1)^popcount(lane & 15) until one repair multiply at the
+    end): 320 MiB in place, random floats and small integers, sampled rows bit-identical to the oracle -- and to the
+    unsigned network (a cached out-of-place launch of the same rows) -- and H.H = D.I exactly on the integers."""
     d = 1 << log2d
-    rows = (320 << 20) // (4 * d) + 3          # + 3: a partial last tile (for D = 2048 the last tile holds one row of two)
+    esize = 4 if dtype == torch.float32 else 8
+    name = "float" if dtype == torch.float32 else "double"
+    bits = torch.int32 if dtype == torch.float32 else torch.int64
+    rows = (320 << 20) // (esize * d) + 3      # + 3: a partial last tile
     g = torch.Generator(device=DEV).manual_seed(log2d)
     idx = torch.cat((torch.tensor([0, 1, 2, 3, rows // 2 + 1, rows - 2, rows - 1]), torch.randint(0, rows, (121,)))).to(DEV)
     for kind in ("randn", "ints"):
         if kind == "randn":
-            x = torch.randn(rows, d, device=DEV, generator=g)
+            x = torch.randn(rows, d, device=DEV, generator=g, dtype=dtype)
         else:
-            x = torch.randint(-3, 4, (rows, d), device=DEV, generator=g, dtype=torch.int32).float()
+            x = torch.randint(-3, 4, (rows, d), device=DEV, generator=g, dtype=torch.int32).to(dtype)
         keep = x[idx].clone()
         _hip.fwht_rows(x, out=x)
-        assert _hip.last_kernel() == f"whvi::fwht_rows_kernel<float, {log2d}, 16, 0, false, true, 256, 1, true>"
+        assert _hip.last_kernel() == f"whvi::fwht_rows_kernel<{name}, {log2d}, 16, 0, false, true, 256, 1, true>", _hip.last_kernel()
         got = x[idx].cpu()
-        assert torch.equal(got.view(torch.int32), _oracle(keep.cpu()).view(torch.int32)), kind
+        assert torch.equal(got.view(bits), _oracle(keep.cpu()).view(bits)), kind
         small = _hip.fwht_rows(keep)                              # 128 rows: the cached, unsigned launch
-        assert _hip.last_kernel().endswith("256, 0, false>") and torch.equal(small.view(torch.int32), got.to(DEV).view(torch.int32))
+        assert _hip.last_kernel().endswith(", 0, false>") and ", false, false, " in _hip.last_kernel()
+        assert torch.equal(small.view(bits), got.to(DEV).view(bits))
         if kind == "ints":
             _hip.fwht_rows(x, out=x)
             assert torch.equal(x[idx], keep * d) and torch.equal(x[::4099], x[::4099].round())

@@ -6,8 +6,8 @@ import torch
 from whvi_amd import _hip
 
 LOG2D = int(sys.argv[1]) if len(sys.argv) > 1 else 12
-SFX = sys.argv[2] if len(sys.argv) > 2 else "f32"           # f32 | f16 | bf16 | i32
-DT = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16, "i32": torch.int32}[SFX]
+SFX = sys.argv[2] if len(sys.argv) > 2 else "f32"           # f32 | f16 | bf16 | i32 | f64
+DT = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16, "i32": torch.int32, "f64": torch.float64}[SFX]
 x = (torch.randn(1 << 30 if LOG2D < 12 else 1 << 32, device="cuda") * 2.0 ** -100).to(DT).view(-1, 1 << LOG2D)
 libs = {"prod": _hip.lib()}
 for path in sorted(glob.glob(os.path.join(os.path.dirname(_hip.LIB_PATH), "_exp", "libexp_*.so")) +

@@ -164,7 +164,17 @@ inline void launch_rows(void *dst, const void *src, int64_t n_chunks, int varian
                 // fall to 5.7: their waves share SIMDs and leave the butterflies microseconds apart); fp16 5.5 ->
                 // 6.2, bf16 5.0 -> 6.1, i32 5.8 -> 6.3 TB/s (tools/probe_stream_blocks.py)
                 static const bool exp_big_blocks = WHVI_TUNE_ENV("WHVI_STREAM_BIG_BLOCKS") != nullptr;   // A/B switch (tuning builds)
-                if (exp_big_blocks || sizeof(T) == 8) WHVI_LAUNCH(POLICY_DPP, false, true, BIG);   // f64, 16 KiB tiles: 6.07 vs 5.93
+                // f64 (64-register tiles, D = 64 .. 2048): 256-thread blocks + store barrier with the SIGNED DPP network (one
+                // fma per lane-stage element instead of a sign fold + an add, one repair multiply at the end): 6.35-6.38 vs
+                // 6.25-6.28 TB/s for the round-2 launch (1024-thread blocks, no barrier), which in turn beats 256 + barrier
+                // with the UNSIGNED network (5.93-5.97) -- gpurun_out r03_ab_f64form*.log; D < 64 keeps the 512-thread form
+                constexpr bool F64_SIGNED = sizeof(T) == 8 && LOG2D >= 6 && WHVI_F64_STREAM_FORM == 2;
+                if (exp_big_blocks || (sizeof(T) == 8 && !F64_SIGNED && WHVI_F64_STREAM_FORM != 1)) WHVI_LAUNCH(POLICY_DPP, false, true, BIG);
+                else if constexpr (F64_SIGNED) {
+                    note_launch<T>("fwht_rows_kernel", LOG2D, K, POLICY_DPP, false, true, 256, 1, true);
+                    hipLaunchKernelGGL((fwht_rows_kernel<T, LOG2D, K, POLICY_DPP, false, true, 256, 1, true>),
+                                       dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, st, d, s, n_chunks, n_tiles);
+                }
                 else if constexpr (sizeof(T) == 2 && K * Elem<T>::VEC == 64)
                     // 16-bit storage: half the bytes per butterfly, so the DPP network's VALU time co-limits the
                     // stream (6.1 TB/s).  The LDS-staged network needs a third of the issue slots: fp16 6.4,
@@ -190,8 +200,9 @@ inline void launch_rows(void *dst, const void *src, int64_t n_chunks, int varian
             // tiles of more than 64 data VGPRs (one row per wave: f32 D = 8192, f64 D = 4096): 256-thread blocks
             // either way; streams get the non-temporal accesses and the store barrier as well
             if (big && nt) {
-                note_launch<T>("fwht_rows_kernel", LOG2D, K, POLICY_DPP, false, true, 256, 1, false);
-                hipLaunchKernelGGL((fwht_rows_kernel<T, LOG2D, K, POLICY_DPP, false, true, 256, 1>),
+                constexpr bool SG = sizeof(T) == 8 && WHVI_F64_STREAM_FORM == 3;   // tuning: the signed network here loses (6.23 vs 6.31)
+                note_launch<T>("fwht_rows_kernel", LOG2D, K, POLICY_DPP, false, true, 256, 1, SG);
+                hipLaunchKernelGGL((fwht_rows_kernel<T, LOG2D, K, POLICY_DPP, false, true, 256, 1, SG>),
                                    dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, st, d, s, n_chunks, n_tiles);
             } else WHVI_LAUNCH(POLICY_DPP, false, false, 256);
         }

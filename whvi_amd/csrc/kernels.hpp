@@ -284,7 +284,7 @@ fwht_rows_kernel(u32x4 *dst, const u32x4 *src, int64_t n_chunks, int64_t n_tiles
         // 6.30-6.33 TB/s at D = 512 / 1024 / 2048 (D = 4096: 6.0-6.4 vs 6.48, so that shape keeps the unsigned
         // network); profiles/r02/plateau_*.
         if constexpr (SIGNED) {
-            static_assert(POLICY == POLICY_DPP && std::is_same<A, float>::value, "signed form: f32 arithmetic, DPP network");
+            static_assert(POLICY == POLICY_DPP && !std::is_same<A, int32_t>::value, "signed form: floating-point arithmetic, DPP network");
             fwht_tile<A, VEC, K, LOG2D, POLICY_DPP, WHVI_ROWS_PKMASK, true, 0>(r, lane);
             constexpr int OUT = fwht_sign_out<VEC, LOG2D>(0);
             const A sg = (__builtin_popcount(lane & OUT) & 1) ? (A)-1 : (A)1;
