@@ -436,3 +436,41 @@ def test_packed_stacked_layer_is_the_same_layer(n_in, n_out, monkeypatch):
     last = sub.stack - 1
     assert torch.equal(loaded.weight_submodule.weight_matrices[last].g_rho, packed.weight_submodule.packed_g_rho[last])
     assert loaded(x * 0).shape == (6, n_out) and torch.equal(loaded.weight_submodule.packed_s2, packed.weight_submodule.packed_s2)
+
+
+def test_fast_training_path_refuses_the_host_clearly(tmp_path):
+    """``make_optimizer(capturable=True)`` and ``train_model(graphed=True)`` are GPU features: on host tensors they say so
+    instead of failing somewhere inside torch; ``packed=True`` after the optimizer exists is refused with the remedy; the
+    plain recipe is untouched by the new keywords (same trajectory with and without them spelled out)."""
+    import copy
+    import torch.nn as nn
+    from torch.utils.data import DataLoader, TensorDataset
+    from whvi_amd.evaluation import make_optimizer
+    from whvi_amd.layers import WHVILinear
+    from whvi_amd.networks import WHVIRegression
+    torch.manual_seed(0)
+    net = WHVIRegression([WHVILinear(3, 8), nn.ReLU(), WHVILinear(8, 1)], train_samples=2)
+    twin = copy.deepcopy(net)
+    x, y = torch.randn(12, 3), torch.randn(12, 1)
+    loader = DataLoader(TensorDataset(x, y), batch_size=6)
+    with pytest.raises(RuntimeError, match="needs the network on a GPU"):
+        make_optimizer(net, capturable=True)
+    optimizer, scheduler = make_optimizer(net, lambda0=0.05)
+    with pytest.raises(RuntimeError, match="needs GPU tensors"):
+        net.train_model(loader, optimizer, scheduler, epochs1=1, epochs2=0, graphed=True)
+    with pytest.raises(RuntimeError, match="BEFORE creating the optimizer"):
+        net.train_model(loader, optimizer, scheduler, epochs1=1, epochs2=0, packed=True)
+    # the reference's call and the same call with every new keyword at its default walk the same trajectory
+    opt2, sched2 = make_optimizer(twin, lambda0=0.05, capturable=False, packed=False)
+    torch.manual_seed(5)
+    net.train_model(loader, optimizer, scheduler, epochs1=1, epochs2=1, checkpoint_dir=tmp_path)
+    torch.manual_seed(5)
+    twin.train_model(loader, opt2, sched2, epochs1=1, epochs2=1, graphed=False, packed=None, sharded=False)
+    for (k, a), (_, b) in zip(net.named_parameters(), twin.named_parameters()):
+        assert torch.equal(a, b), k
+    # packed layout chosen through make_optimizer: 4 tensors per stacked layer, the reference's checkpoint keys
+    third = WHVIRegression([WHVILinear(3, 8), nn.ReLU(), WHVILinear(8, 1)], train_samples=2)
+    keys = list(third.state_dict().keys())
+    opt3, sched3 = make_optimizer(third, packed=True)
+    assert len(list(third.parameters())) < len(keys) and list(third.state_dict().keys()) == keys
+    third.train_model(loader, opt3, sched3, epochs1=1, epochs2=0, packed=True)
