@@ -157,6 +157,12 @@ int whvi_fused_shs_f64(void *dst, const void *src, const void *a, const void *b,
  * i.e. every "sample" s carries its own s1 / s2 / u.  flags == 0 is whvi_fused_shs_<dtype>. */
 #define WHVI_FUSED_A_PER_SAMPLE 1
 #define WHVI_FUSED_C_PER_SAMPLE 2
+/* WHVI_FUSED_SRC_SHARED (axis = COL, D * sizeof >= 1 KiB, dst != src): src holds the rows of ONE sample -- sample_stride rows
+ * -- shared by all samples; row r of dst is computed from src row r % sample_stride.  With rows in (sample, batch, D)
+ * order (sample_stride = batch) this is a layer's first Monte-Carlo pass on a (batch, D) input: the input is read from
+ * the caches instead of being expanded to (n_samples, batch, D) in HBM first.  Same arithmetic per row: same bits as the
+ * launch on the expanded input. */
+#define WHVI_FUSED_SRC_SHARED   4
 
 int whvi_fused_shs_ex_f32(void *dst, const void *src, const void *a, const void *b,
                           const void *c, int64_t rows, int32_t log2d, int64_t n_samples,

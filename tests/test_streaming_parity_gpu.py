@@ -187,3 +187,34 @@ def test_int32_wraps_like_the_reference(in_place, hip_lib):
     # H.H = 4096.I modulo 2^32 on the whole buffer
     back = _hip.fwht_rows(y)
     assert torch.equal(back, keep * 4096)
+
+
+@pytest.mark.parametrize("dtype,log2d,B", [(torch.float32, 11, 8192), (torch.float32, 12, 1028), (torch.float32, 8, 4096 * 5 + 3),
+                                           (torch.float64, 11, 1024), (torch.float64, 12, 516), (torch.float32, 9, 33)])
+def test_shared_source_equals_the_expanded_launch(dtype, log2d, B, hip_lib):
+    """WHVI_FUSED_SRC_SHARED: a (batch, D) input shared by all MC samples (a fastfood layer's first pass) is read by every
+    sample from the caches instead of being expanded to (S, batch, D) first.  Bit-equal to the launch on the expanded
+    input (whose instantiations the test above pins to the oracle) and, on sampled rows, to ``oracle.pipeline`` directly;
+    BASELINE config 3's shape (D = 2048, batch 8192, 64 samples: 4 GiB written) included, batches that are and are not
+    multiples of the rows per block, a launch below the streaming threshold, the source left untouched."""
+    d, S = 1 << log2d, 64 if B >= 512 else 5
+    g = torch.Generator(device=DEV).manual_seed(log2d * 131 + B)
+    x = torch.randn(B, d, device=DEV, dtype=dtype, generator=g)
+    a, c = (torch.randn(d, device=DEV, dtype=dtype, generator=g) * 0.1 for _ in range(2))
+    b = torch.randn(S, d, device=DEV, dtype=dtype, generator=g)
+    keep = x.clone()
+    got = _hip.fused_shs(x, a, b, c, axis="col", n_samples=S, sample_stride=B, src_shared=True)
+    symbol = _hip.last_kernel()
+    assert symbol.endswith(", true>") and symbol.count(",") == 9, symbol              # the SHARED_SRC instantiation
+    assert got.shape == (S * B, d) and torch.equal(x, keep)
+    rows = S * B
+    rng = np.random.default_rng(B)
+    idx = np.unique(np.clip(np.concatenate([[0, 1, B - 1, B, B + 1, 2 * B - 1, rows - B, rows - 1], rng.integers(0, rows, 70)]), 0, rows - 1))
+    want = oracle.pipeline(x[torch.from_numpy(idx % B).to(DEV)].cpu().numpy(), a.cpu().numpy(), b.cpu().numpy()[idx // B],
+                           c.cpu().numpy(), n_samples=len(idx), sample_stride=1, axis="col")
+    assert np.array_equal(_bits(got[torch.from_numpy(idx).to(DEV)].cpu().numpy()), _bits(want))
+    expanded = _hip.fused_shs(x.repeat(S, 1), a, b, c, axis="col", n_samples=S, sample_stride=B)
+    assert _hip.last_kernel().count(",") == 8
+    assert torch.equal(got.view(torch.uint8), expanded.view(torch.uint8))
+    with pytest.raises(RuntimeError, match="src_shared needs"):
+        _hip.fused_shs(torch.zeros(4, 64, device=DEV), a[:64], b[:, :64], c[:64], axis="col", n_samples=S, sample_stride=4, src_shared=True)

@@ -203,7 +203,12 @@ def fwht_rows(src: torch.Tensor, out: torch.Tensor = None, variant: int = None) 
     return out
 
 
-FUSED_A_PER_SAMPLE, FUSED_C_PER_SAMPLE = 1, 2
+FUSED_A_PER_SAMPLE, FUSED_C_PER_SAMPLE, FUSED_SRC_SHARED = 1, 2, 4
+
+
+def fused_src_shared_supported(dtype: torch.dtype, d: int) -> bool:
+    """Row lengths the shared-source form of ``whvi_fused_shs_*`` covers (rows of at least 64 sixteen-byte chunks)."""
+    return fused_supported(dtype, d) and d * (4 if dtype == torch.float32 else 8) >= 1024
 
 
 def fused_supported(dtype: torch.dtype, d: int) -> bool:
@@ -217,11 +222,13 @@ def fused_supported(dtype: torch.dtype, d: int) -> bool:
 def fused_shs(src, a=None, b=None, c=None, *, axis: str = "col", n_samples: int = 1,
               sample_stride: int = 1, group_rows: int = 1, rows: int = None, d: int = None,
               dtype=None, device=None, out: torch.Tensor = None, a_per_sample: bool = False,
-              c_per_sample: bool = False) -> torch.Tensor:
+              c_per_sample: bool = False, src_shared: bool = False) -> torch.Tensor:
     """out[r] = a (.) FWHT(b_s (.) FWHT(c (.) src[r])) in ONE kernel (include/whvi_hip.h).
 
     ``src=None`` (axis="row", group_rows == d) synthesises the identity matrix per group, so
     with ``c = s2`` the input is ``torch.diag(s2)`` of src/weights.py:73 without reading HBM.
+    ``src_shared`` (axis="col"): ``src`` is ``(sample_stride, d)`` -- ONE sample's rows, shared by all ``n_samples``
+    samples -- and the result has ``n_samples * sample_stride`` rows in (sample, row) order (WHVI_FUSED_SRC_SHARED).
     """
     ax = {"row": AXIS_ROW, "col": AXIS_COL}[axis]
     if src is not None:
@@ -230,6 +237,10 @@ def fused_shs(src, a=None, b=None, c=None, *, axis: str = "col", n_samples: int 
         src = _aligned(src)
         rows, d = src.shape
         dtype, device = src.dtype, src.device
+        if src_shared:
+            if ax != AXIS_COL or rows != sample_stride or not fused_src_shared_supported(dtype, d):
+                raise RuntimeError("fused_shs: src_shared needs axis='col', src of sample_stride rows and rows of >= 1 KiB")
+            rows = n_samples * sample_stride
     if dtype not in (torch.float32, torch.float64):
         raise RuntimeError("fused_shs: float32 / float64 only")
     if d < 1 or (d & (d - 1)) != 0:
@@ -248,7 +259,8 @@ def fused_shs(src, a=None, b=None, c=None, *, axis: str = "col", n_samples: int 
     a_ = prep(a, unit * (n_samples if a_per_sample else 1))
     b_ = prep(b, unit * n_samples)
     c_ = prep(c, unit * (n_samples if c_per_sample else 1))
-    flags = (FUSED_A_PER_SAMPLE if a_per_sample else 0) | (FUSED_C_PER_SAMPLE if c_per_sample else 0)
+    flags = ((FUSED_A_PER_SAMPLE if a_per_sample else 0) | (FUSED_C_PER_SAMPLE if c_per_sample else 0) |
+             (FUSED_SRC_SHARED if src_shared else 0))
     if out is None:
         out = torch.empty((rows, d), dtype=dtype, device=device)
     elif not out.is_contiguous() or tuple(out.shape) != (rows, d) or out.dtype != dtype:

@@ -20,8 +20,8 @@ struct LaunchNote {
     const char *family = nullptr;     // "fwht_rows_kernel", "fused_shs_kernel", ...
     const char *type = nullptr;
     int n = 0;                        // template arguments after the type
-    int arg[8] = {0};
-    unsigned char is_bool[8] = {0};
+    int arg[12] = {0};
+    unsigned char is_bool[12] = {0};
 };
 extern thread_local LaunchNote g_note;
 template <typename T> constexpr const char *type_name()
@@ -41,8 +41,9 @@ inline void note_launch(const char *family, A... a)
     const NB args[] = {nb(a)...};
     g_note.family = family;
     g_note.type = type_name<T>();
+    static_assert(sizeof...(A) <= 12, "LaunchNote holds twelve template arguments");
     g_note.n = (int)sizeof...(A);
-    for (int i = 0; i < (int)sizeof...(A) && i < 8; ++i) {
+    for (int i = 0; i < (int)sizeof...(A) && i < 12; ++i) {
         g_note.arg[i] = args[i].v;
         g_note.is_bool[i] = args[i].b;
     }
@@ -435,9 +436,21 @@ inline void launch_fused(void *dst, const void *src, const void *a, const void *
                   dg = make_fastdiv((uint32_t)group_rows);
     // "big": enough tiles to fill the chip several times over (32 per CU; 16 for the 32 KiB tiles of one f64 row of 4096)
     const bool big = n_tiles >= (int64_t)(SMALL_TILE ? 32 : 16) * num_cu();
-    const bool nt = big && stream_sized(n_chunks * 16, dst, src);
+    // (a shared source is small and cache-resident by intent: the streamed bytes are the destination's)
+    const bool nt = big && stream_sized(n_chunks * 16, dst, (flags & WHVI_FUSED_SRC_SHARED) ? nullptr : src);
 #define WHVI_FUSED(AX, EYE, NT, BLK, POL, STG)                                                          \
     do {                                                                                                \
+        if constexpr (AX == WHVI_AXIS_COL && !(EYE) && POL == POLICY_DPP && LOG2D - ilog2(VEC) >= 6) {  \
+            if (flags & WHVI_FUSED_SRC_SHARED) {                                                        \
+                note_launch<T>("fused_shs_kernel", LOG2D, K, (int)AX, (bool)EYE, (bool)NT, (int)BLK, (int)POL, (int)STG, true); \
+                constexpr size_t smem_s = (((STG) == STAGE_ABC ? 3 : ((STG) == STAGE_AC ? 2 : 0)) * sizeof(typename Elem<T>::acc) << LOG2D); \
+                hipLaunchKernelGGL((fused_shs_kernel<T, LOG2D, K, AX, EYE, NT, BLK, POL, STG, true>),   \
+                                   dim3((unsigned)((n_tiles + (BLK / 64) - 1) / (BLK / 64))), dim3(BLK), smem_s, st, \
+                                   (u32x4 *)dst, (const u32x4 *)src, (const T *)a, (const T *)b, (const T *)c, \
+                                   n_chunks, n_tiles, ds, dn, dg, flags, same_sample_blocks);           \
+                break;                                                                                  \
+            }                                                                                           \
+        }                                                                                               \
         note_launch<T>("fused_shs_kernel", LOG2D, K, (int)AX, (bool)EYE, (bool)NT, (int)BLK, (int)POL, (int)STG); \
         constexpr size_t smem = ((POL == POLICY_LDS) ? (size_t)(BLK / 64) * slab_bytes : 0) +           \
                                 (((STG) == STAGE_ABC ? 3 : ((STG) == STAGE_AC ? 2 : 0)) * sizeof(typename Elem<T>::acc) << LOG2D); \
@@ -481,8 +494,11 @@ inline void launch_fused(void *dst, const void *src, const void *a, const void *
     constexpr const char *tune_env = nullptr;
 #endif
     int stage = STAGE_NONE;
+    if ((flags & WHVI_FUSED_SRC_SHARED) && rows_per_block >= 1 && sample_stride % rows_per_block == 0 &&
+        rows == n_samples * sample_stride && ((sample_stride / rows_per_block) & 7) == 0 && n_samples > 1)
+        same_sample_blocks = 2;        // shared source: sample index fastest within an XCD (kernels.hpp)
     if (big) {
-        if (one_sample_blocks || flags == 0) stage = STAGE_AC;
+        if (one_sample_blocks || (flags & (WHVI_FUSED_A_PER_SAMPLE | WHVI_FUSED_C_PER_SAMPLE)) == 0) stage = STAGE_AC;
         // per-sample a / c with rows in (batch, sample, D) order and one 128-register row per tile (f64 D = 4096): let every
         // block take four rows of the same sample, S rows apart, and stage that sample's vectors (kernels.hpp).  Measured
         // (4 GiB, 64 samples): 3.83 -> 4.63 TB/s.  NOT for 64-register one-row tiles (f32 D = 4096, f64 D = 2048): there
@@ -498,7 +514,7 @@ inline void launch_fused(void *dst, const void *src, const void *a, const void *
     if (tune_env != nullptr) {
         use_nt = tune_env[2] != '0';
         const int want = tune_env[3] - '0';
-        if (want == STAGE_NONE || (want == STAGE_AC && (flags == 0 || one_sample_blocks)) || (want == STAGE_ABC && one_sample_blocks)) {
+        if (want == STAGE_NONE || (want == STAGE_AC && ((flags & 3) == 0 || one_sample_blocks)) || (want == STAGE_ABC && one_sample_blocks)) {
             stage = want;
             same_sample_blocks = 0;
         }
@@ -552,12 +568,24 @@ inline int fused_dispatch(void *dst, const void *src, const void *a, const void 
                           int64_t group_rows, int32_t axis, int32_t flags, void *stream)
 {
     constexpr int LV = ilog2(Elem<T>::VEC);
-    int rc = check_common(dst, src, rows, log2d, max_single_pass_log2d<T>(), sizeof(T), true);
+    // a shared source (WHVI_FUSED_SRC_SHARED) is sample_stride rows long, not `rows`: its overlap check is done below
+    const bool shared_src = (flags & WHVI_FUSED_SRC_SHARED) != 0 && src != nullptr;
+    int rc = check_common(dst, shared_src ? nullptr : src, rows, log2d, max_single_pass_log2d<T>(), sizeof(T), true);
     if (rc != WHVI_OK) return rc;
+    if (shared_src && rows > 0) {
+        if ((uintptr_t)src & 15) return fail(WHVI_ERR_ALIGN, "whvi: %s pointer is not 16-byte aligned", "src");
+        const char *d = (const char *)dst, *sp = (const char *)src;
+        const int64_t dbytes = (rows << log2d) * (int64_t)sizeof(T), sbytes = (sample_stride << log2d) * (int64_t)sizeof(T);
+        if (sample_stride >= 1 && d < sp + sbytes && sp < d + dbytes)
+            return fail(WHVI_ERR_OVERLAP, "whvi: dst overlaps the shared source%s", "");
+    }
     if (axis != WHVI_AXIS_ROW && axis != WHVI_AXIS_COL)
         return fail(WHVI_ERR_ARG, "whvi: bad axis%s %lld", "", axis);
-    if (flags & ~(WHVI_FUSED_A_PER_SAMPLE | WHVI_FUSED_C_PER_SAMPLE))
+    if (flags & ~(WHVI_FUSED_A_PER_SAMPLE | WHVI_FUSED_C_PER_SAMPLE | WHVI_FUSED_SRC_SHARED))
         return fail(WHVI_ERR_ARG, "whvi: unknown fused flags%s 0x%llx", "", flags);
+    if ((flags & WHVI_FUSED_SRC_SHARED) && (src == nullptr || dst == src || axis != WHVI_AXIS_COL || log2d - LV < 6))
+        return fail(WHVI_ERR_ARG, "whvi: the shared-source flag needs axis = COL, src != NULL, dst != src and rows of at least "
+                    "64 sixteen-byte chunks%s", "");
     if (n_samples < 1 || sample_stride < 1 || group_rows < 1)
         return fail(WHVI_ERR_ARG, "whvi: n_samples, sample_stride and group_rows must be >= 1%s", "");
     if (rows >= ((int64_t)1 << 32) || n_samples >= ((int64_t)1 << 32) || sample_stride >= ((int64_t)1 << 32) ||

@@ -679,8 +679,11 @@ inline FastDiv make_fastdiv(uint32_t d)
 //   STAGE_ABC   a, b and c of the block's one sample (same condition): no scale vector comes through L2 -> L1 at all.
 constexpr int STAGE_NONE = 0, STAGE_AC = 1, STAGE_ABC = 3;
 
+// SHARED_SRC (WHVI_FUSED_SRC_SHARED; AXIS_COL, rows of >= 64 chunks): src holds the rows of ONE sample -- sample_stride of
+// them -- shared by all samples, row r reads src row r mod sample_stride.  The (batch, D) input of a layer's first
+// Monte-Carlo pass is then read from the caches instead of being expanded to (S, batch, D) in HBM first.
 template <typename T, int LOG2D, int K, int AXIS, bool EYE, bool NT, int BLOCK, int POLICY = POLICY_DPP,
-          int STAGE = STAGE_NONE>
+          int STAGE = STAGE_NONE, bool SHARED_SRC = false>
 __global__ void __launch_bounds__(BLOCK)
 fused_shs_kernel(u32x4 *dst, const u32x4 *src, const T *a, const T *b, const T *c,
                  int64_t n_chunks, int64_t n_tiles, FastDiv by_sample_stride, FastDiv by_n_samples,
@@ -702,6 +705,15 @@ fused_shs_kernel(u32x4 *dst, const u32x4 *src, const T *a, const T *b, const T *
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // streams: XCD-contiguous block order and a block barrier before the stores, as in fwht_rows_kernel
     int64_t blk = blockIdx.x;
+    if (SHARED_SRC && same_sample_blocks == 2u) {
+        // shared source, sample index FASTEST within an XCD (host: whole blocks per sample, blocks per sample a multiple of
+        // 8): blocks are dealt round-robin over the 8 XCDs; XCD x takes row groups x, x + 8, ... and runs each of them for
+        // all samples back to back, so a source tile is fetched into that XCD's L2 once and hit n_samples - 1 times
+        // (sample-major order re-reads the whole source per sample from the Infinity Cache: as many fabric bytes in as out)
+        const uint32_t b = blockIdx.x, xcd = b & 7u, i = b >> 3;
+        const uint32_t q = by_n_samples.div(i), smp = i - q * by_n_samples.d;
+        blk = (int64_t)smp * (gridDim.x / by_n_samples.d) + (q * 8u + xcd);
+    } else
     if (NT && (gridDim.x & 7) == 0) blk = (blk & 7) * (int64_t)(gridDim.x >> 3) + (blk >> 3);
     int64_t t = blk * (BLOCK / 64) + wave;
     // same_sample_blocks (host: rows in (batch, sample, D) order, one row per tile, whole groups of 4 x n_samples rows,
@@ -776,6 +788,17 @@ fused_shs_kernel(u32x4 *dst, const u32x4 *src, const T *a, const T *b, const T *
         // 5.95: the branch costs the 128-register tile its second wave per SIMD) and keep the bounds-checked buffer loads,
         // as do the partial last tile and idle waves everywhere.  gpurun_out r03_ab_{prod,tl1,tl2}.log
         constexpr bool GLOBAL_TILE_LOADS = WHVI_FUSED_TILE_LOADS >= 0 ? WHVI_FUSED_TILE_LOADS == 1 : (sizeof(A) == 4 || LOG2D <= 10);
+        if constexpr (SHARED_SRC) {
+            static_assert(AXIS == WHVI_AXIS_COL && SH >= 6, "shared source: column axis, rows of >= 64 chunks");
+            constexpr int KPR = (int)CPR / 64;                       // k-steps per row
+            if (active) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const uint32_t srow = by_sample_stride.mod(row0 + (uint32_t)(k / KPR));      // wave-uniform
+                    raw[k] = ld16<false>(src + (int64_t)srow * CPR + (k % KPR) * 64 + lane);     // cached: meant to be resident
+                }
+            }
+        } else
         if (GLOBAL_TILE_LOADS && tile_bytes == TILE * 16) {
 #pragma unroll
             for (int k = 0; k < K; ++k) raw[k] = ld16<NT>(src + base + k * 64 + lane);

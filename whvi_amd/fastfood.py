@@ -35,8 +35,17 @@ def _fwht(x):
     return fwht_cpp.forward(x)
 
 
-def _pipeline(x, a, b, c, n_samples, sample_stride):
-    """a * fwht(b[s(r)] * fwht(c * x[r])) for every row r, s(r) = (r // sample_stride) % n_samples."""
+def _pipeline(x, a, b, c, n_samples, sample_stride, shared=False):
+    """a * fwht(b[s(r)] * fwht(c * x[r])) for every row r, s(r) = (r // sample_stride) % n_samples.  ``shared``: ``x`` holds
+    ONE sample's rows (``sample_stride`` of them) and every sample reads them -- on the GPU straight from the caches
+    (WHVI_FUSED_SRC_SHARED), elsewhere after expanding."""
+    if shared:
+        if x.device.type == "cuda":
+            from whvi_amd import _hip
+            if _hip.fused_src_shared_supported(x.dtype, x.size(1)):
+                return _hip.fused_shs(x, a, b, c, axis="col", n_samples=n_samples, sample_stride=sample_stride,
+                                      src_shared=True)
+        x = x.repeat(n_samples, 1)
     if x.device.type == "cuda":
         from whvi_amd import _hip
         if _hip.fused_supported(x.dtype, x.size(1)):
@@ -55,10 +64,12 @@ class FastfoodFunction(torch.autograd.Function):
     intermediate transforms (recomputed, not stored) summed over rows.  First order only."""
 
     @staticmethod
-    def forward(ctx, x, a, b, c, n_samples, sample_stride):
+    def forward(ctx, x, a, b, c, n_samples, sample_stride, shared=False):
+        """``shared``: ``x`` is ``(sample_stride, D)``, the same rows for every sample (a layer's first Monte-Carlo pass on
+        a ``(batch, D)`` input); the result still has ``n_samples * sample_stride`` rows."""
         ctx.save_for_backward(x, a, b, c)
-        ctx.n_samples, ctx.sample_stride = int(n_samples), int(sample_stride)
-        return _pipeline(x, a, b, c, ctx.n_samples, ctx.sample_stride)
+        ctx.n_samples, ctx.sample_stride, ctx.shared = int(n_samples), int(sample_stride), bool(shared)
+        return _pipeline(x, a, b, c, ctx.n_samples, ctx.sample_stride, ctx.shared)
 
     @staticmethod
     @once_differentiable
@@ -68,8 +79,14 @@ class FastfoodFunction(torch.autograd.Function):
         grad_y = grad_y.contiguous()
         need_x, need_a, need_b, need_c = ctx.needs_input_grad[:4]
         grad_x = grad_a = grad_b = grad_c = None
+        if ctx.shared:
+            # every sample read the same rows: their gradients add up (what autograd does for an expanded input)
+            fold = lambda g: None if g is None else g.view(S, stride, -1).sum(dim=0)   # noqa: E731
+            x = x.repeat(S, 1)
+        else:
+            fold = lambda g: g                                                        # noqa: E731
         if need_x and not (need_a or need_b or need_c):
-            return _pipeline(grad_y, c, b, a, S, stride), None, None, None, None, None
+            return fold(_pipeline(grad_y, c, b, a, S, stride)), None, None, None, None, None, None
         rows = torch.arange(x.size(0), device=x.device) // stride % S
         b_rows = b[rows]
         t1 = _fwht(c * x)                                   # forward intermediates, recomputed
@@ -87,8 +104,8 @@ class FastfoodFunction(torch.autograd.Function):
             if need_c:
                 grad_c = (w * x).sum(dim=0)
             if need_x:
-                grad_x = c * w
-        return grad_x, grad_a, grad_b, grad_c, None, None
+                grad_x = fold(c * w)
+        return grad_x, grad_a, grad_b, grad_c, None, None, None
 
 
 class WHVIFastfoodMatrix(nn.Module):
@@ -130,7 +147,11 @@ class WHVIFastfoodMatrix(nn.Module):
         eps = torch.randn(n_samples, self.D, device=self.g_mu.device)
         g = self.g_mu + self.g_sigma * eps                                        # (S, D)
         if x.dim() == 2:
-            x = x.unsqueeze(0).expand(n_samples, -1, -1)
+            # a (batch, D) input shared by all samples: read by every sample straight from the caches, never expanded
+            batch = x.size(0)
+            out = FastfoodFunction.apply(x.contiguous(), self.s1, g, self.s2, n_samples, batch, True)
+            out = out.view(n_samples, batch, self.D)
+            return out + self.bias if self.bias is not None else out
         batch = x.size(1)
         rows = x.reshape(n_samples * batch, self.D).contiguous()
         out = FastfoodFunction.apply(rows, self.s1, g, self.s2, n_samples, batch).view(n_samples, batch, self.D)
