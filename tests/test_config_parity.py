@@ -579,3 +579,29 @@ def test_weight_construction_at_streaming_size(D, S, hip_lib):
     off = full[0, S - 1].clone()
     off.diagonal().zero_()
     assert float(off.abs().max()) == 0.0                                          # exactly diagonal (SURVEY finding 1)
+
+
+@pytest.mark.gpu
+def test_graphed_training_with_a_ragged_last_batch(hip_lib):
+    """``train_model(graphed=True)`` on a data set whose last batch is short (20 rows in batches of 8: 8, 8, 4): the full
+    batches are hipGraph replays, the short one takes the eager step BESIDE the captured one -- detached from the graph's
+    static gradient buffers first, or its backward would accumulate into what the last replay left there.  Same generator
+    seed -> the run equals the all-eager run of the same recipe (same draws in the same order), every step counted by the
+    device-resident schedule."""
+    import copy
+    torch.manual_seed(8)
+    net = WHVIRegression([WHVILinear(3, 16, lambda_=2.0), nn.ReLU(), WHVILinear(16, 16, lambda_=2.0), nn.ReLU(),
+                          WHVILinear(16, 1, lambda_=2.0)], train_samples=2).to("cuda")
+    twin = copy.deepcopy(net)
+    X, Y = torch.randn(20, 3, device="cuda"), torch.randn(20, 1, device="cuda")
+    loader = DataLoader(TensorDataset(X, Y), batch_size=8)
+    opt, sched = make_optimizer(net, lambda0=0.05, capturable=True)
+    opt2, sched2 = make_optimizer(twin, lambda0=0.05, capturable=True)
+    torch.manual_seed(77)
+    step = net.train_model(loader, opt, sched, epochs1=2, epochs2=2, graphed=True)
+    assert step is not None and float(sched.t) == 12.0                     # 4 epochs x 3 batches, replayed or eager
+    torch.manual_seed(77)
+    twin.train_model(loader, opt2, sched2, epochs1=2, epochs2=2)           # the same recipe, all eager
+    assert float(sched2.t) == 12.0 and abs(sched.get_last_lr()[0] - sched2.get_last_lr()[0]) < 1e-12
+    for (k, a), (_, b) in zip(net.named_parameters(), twin.named_parameters()):
+        assert bool(torch.isfinite(a).all()) and torch.allclose(a, b, rtol=1e-4, atol=1e-6), k
