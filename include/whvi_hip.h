@@ -163,6 +163,12 @@ int whvi_fused_shs_f64(void *dst, const void *src, const void *a, const void *b,
  * the caches instead of being expanded to (n_samples, batch, D) in HBM first.  Same arithmetic per row: same bits as the
  * launch on the expanded input. */
 #define WHVI_FUSED_SRC_SHARED   4
+/* WHVI_FUSED_ONE_TRANSFORM (axis = COL, D * sizeof >= 1 KiB, c == NULL): dst = A (.) FWHT(B_s (.) src) -- the second half of
+ * the pipeline on its own (matmul_diag . fwht, src/utils.py:15-23 + src/fwht).  For a source shared by all samples the
+ * first half FWHT(C (.) x) is sample-independent: compute it once (this entry with b = C, n_samples = 1), then every
+ * sample with WHVI_FUSED_SRC_SHARED | WHVI_FUSED_ONE_TRANSFORM -- one transform per sample instead of two, the same
+ * multiplies and butterflies in the same order, hence the same bits as the two-transform launch. */
+#define WHVI_FUSED_ONE_TRANSFORM 8
 
 int whvi_fused_shs_ex_f32(void *dst, const void *src, const void *a, const void *b,
                           const void *c, int64_t rows, int32_t log2d, int64_t n_samples,

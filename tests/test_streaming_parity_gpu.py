@@ -205,7 +205,7 @@ def test_shared_source_equals_the_expanded_launch(dtype, log2d, B, hip_lib):
     keep = x.clone()
     got = _hip.fused_shs(x, a, b, c, axis="col", n_samples=S, sample_stride=B, src_shared=True)
     symbol = _hip.last_kernel()
-    assert symbol.endswith(", true>") and symbol.count(",") == 9, symbol              # the SHARED_SRC instantiation
+    assert symbol.endswith(", true, false>") and symbol.count(",") == 10, symbol      # the SHARED_SRC instantiation
     assert got.shape == (S * B, d) and torch.equal(x, keep)
     rows = S * B
     rng = np.random.default_rng(B)
@@ -216,5 +216,14 @@ def test_shared_source_equals_the_expanded_launch(dtype, log2d, B, hip_lib):
     expanded = _hip.fused_shs(x.repeat(S, 1), a, b, c, axis="col", n_samples=S, sample_stride=B)
     assert _hip.last_kernel().count(",") == 8
     assert torch.equal(got.view(torch.uint8), expanded.view(torch.uint8))
+    # WHVI_FUSED_ONE_TRANSFORM: fwht(c * x) ONCE, then one transform per sample on the shared result -- the same bits
+    t = _hip.fused_shs(x, None, c.reshape(1, -1), None, axis="col", n_samples=1, one_transform=True)
+    assert _hip.last_kernel().endswith(", false, true>"), _hip.last_kernel()
+    assert torch.equal(t, _hip.fwht_rows(c * x)), "scale -> FWHT alone == a multiply and the plain transform"
+    halves = _hip.fused_shs(t, a, b, None, axis="col", n_samples=S, sample_stride=B, src_shared=True, one_transform=True)
+    assert _hip.last_kernel().endswith(", true, true>"), _hip.last_kernel()
+    assert torch.equal(halves.view(torch.uint8), got.view(torch.uint8))
+    with pytest.raises(RuntimeError, match="one_transform needs"):
+        _hip.fused_shs(x, a, b, c, axis="col", n_samples=S, sample_stride=B, one_transform=True)
     with pytest.raises(RuntimeError, match="src_shared needs"):
         _hip.fused_shs(torch.zeros(4, 64, device=DEV), a[:64], b[:, :64], c[:64], axis="col", n_samples=S, sample_stride=4, src_shared=True)

@@ -19,6 +19,12 @@ for d, B in ((2048, 8192), (4096, 4096), (512, 32768)):
     out = torch.empty(S * B, d, device=dev)
     ms = timed(lambda: _hip.fused_shs(x, a, g, c, axis="col", n_samples=S, sample_stride=B, src_shared=True, out=out))
     k = _hip.last_kernel()
+    t = _hip.fused_shs(x, None, c.reshape(1, -1), None, axis="col", n_samples=1, one_transform=True)
+    ms1 = timed(lambda: _hip.fused_shs(t, a, g, None, axis="col", n_samples=S, sample_stride=B, src_shared=True, one_transform=True, out=out))
+    k1 = _hip.last_kernel()
+    ms0 = timed(lambda: _hip.fused_shs(x, None, c.reshape(1, -1), None, axis="col", n_samples=1, one_transform=True))
+    print(f"D={d} B={B}: one transform per sample on the shared first half {ms1:.3f} ms = {out.numel() * 4 / 1e6 / ms1:7.1f} GB/s written "
+          f"(+ the first half once: {ms0 * 1e3:.1f} us)   {k1[6:]}")
     xe = x.repeat(S, 1)
     ms2 = timed(lambda: _hip.fused_shs(xe, a, g, c, axis="col", n_samples=S, sample_stride=B, out=out))
     wr = out.numel() * 4 / 1e6

@@ -203,7 +203,7 @@ def fwht_rows(src: torch.Tensor, out: torch.Tensor = None, variant: int = None) 
     return out
 
 
-FUSED_A_PER_SAMPLE, FUSED_C_PER_SAMPLE, FUSED_SRC_SHARED = 1, 2, 4
+FUSED_A_PER_SAMPLE, FUSED_C_PER_SAMPLE, FUSED_SRC_SHARED, FUSED_ONE_TRANSFORM = 1, 2, 4, 8
 
 
 def fused_src_shared_supported(dtype: torch.dtype, d: int) -> bool:
@@ -222,13 +222,14 @@ def fused_supported(dtype: torch.dtype, d: int) -> bool:
 def fused_shs(src, a=None, b=None, c=None, *, axis: str = "col", n_samples: int = 1,
               sample_stride: int = 1, group_rows: int = 1, rows: int = None, d: int = None,
               dtype=None, device=None, out: torch.Tensor = None, a_per_sample: bool = False,
-              c_per_sample: bool = False, src_shared: bool = False) -> torch.Tensor:
+              c_per_sample: bool = False, src_shared: bool = False, one_transform: bool = False) -> torch.Tensor:
     """out[r] = a (.) FWHT(b_s (.) FWHT(c (.) src[r])) in ONE kernel (include/whvi_hip.h).
 
     ``src=None`` (axis="row", group_rows == d) synthesises the identity matrix per group, so
     with ``c = s2`` the input is ``torch.diag(s2)`` of src/weights.py:73 without reading HBM.
     ``src_shared`` (axis="col"): ``src`` is ``(sample_stride, d)`` -- ONE sample's rows, shared by all ``n_samples``
     samples -- and the result has ``n_samples * sample_stride`` rows in (sample, row) order (WHVI_FUSED_SRC_SHARED).
+    ``one_transform`` (axis="col", ``c`` must be None): ``out[r] = a (.) FWHT(b_s (.) src[r])``, the second half alone.
     """
     ax = {"row": AXIS_ROW, "col": AXIS_COL}[axis]
     if src is not None:
@@ -259,8 +260,10 @@ def fused_shs(src, a=None, b=None, c=None, *, axis: str = "col", n_samples: int 
     a_ = prep(a, unit * (n_samples if a_per_sample else 1))
     b_ = prep(b, unit * n_samples)
     c_ = prep(c, unit * (n_samples if c_per_sample else 1))
+    if one_transform and (c is not None or ax != AXIS_COL or src is None or not fused_src_shared_supported(dtype, d)):
+        raise RuntimeError("fused_shs: one_transform needs axis='col', a source, c=None and rows of >= 1 KiB")
     flags = ((FUSED_A_PER_SAMPLE if a_per_sample else 0) | (FUSED_C_PER_SAMPLE if c_per_sample else 0) |
-             (FUSED_SRC_SHARED if src_shared else 0))
+             (FUSED_SRC_SHARED if src_shared else 0) | (FUSED_ONE_TRANSFORM if one_transform else 0))
     if out is None:
         out = torch.empty((rows, d), dtype=dtype, device=device)
     elif not out.is_contiguous() or tuple(out.shape) != (rows, d) or out.dtype != dtype:

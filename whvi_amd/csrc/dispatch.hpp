@@ -440,14 +440,21 @@ inline void launch_fused(void *dst, const void *src, const void *a, const void *
     const bool nt = big && stream_sized(n_chunks * 16, dst, (flags & WHVI_FUSED_SRC_SHARED) ? nullptr : src);
 #define WHVI_FUSED(AX, EYE, NT, BLK, POL, STG)                                                          \
     do {                                                                                                \
-        if constexpr (AX == WHVI_AXIS_COL && !(EYE) && POL == POLICY_DPP && LOG2D - ilog2(VEC) >= 6) {  \
-            if (flags & WHVI_FUSED_SRC_SHARED) {                                                        \
-                note_launch<T>("fused_shs_kernel", LOG2D, K, (int)AX, (bool)EYE, (bool)NT, (int)BLK, (int)POL, (int)STG, true); \
-                constexpr size_t smem_s = (((STG) == STAGE_ABC ? 3 : ((STG) == STAGE_AC ? 2 : 0)) * sizeof(typename Elem<T>::acc) << LOG2D); \
-                hipLaunchKernelGGL((fused_shs_kernel<T, LOG2D, K, AX, EYE, NT, BLK, POL, STG, true>),   \
-                                   dim3((unsigned)((n_tiles + (BLK / 64) - 1) / (BLK / 64))), dim3(BLK), smem_s, st, \
-                                   (u32x4 *)dst, (const u32x4 *)src, (const T *)a, (const T *)b, (const T *)c, \
-                                   n_chunks, n_tiles, ds, dn, dg, flags, same_sample_blocks);           \
+        if constexpr (AX == WHVI_AXIS_COL && !(EYE) && POL == POLICY_DPP && LOG2D - ilog2(VEC) >= 6 && (STG) != STAGE_ABC) { \
+            if (flags & (WHVI_FUSED_SRC_SHARED | WHVI_FUSED_ONE_TRANSFORM)) {                           \
+                constexpr size_t smem_s = (((STG) == STAGE_AC ? 2 : 0) * sizeof(typename Elem<T>::acc) << LOG2D); \
+                const bool shared_ = (flags & WHVI_FUSED_SRC_SHARED) != 0, one_ = (flags & WHVI_FUSED_ONE_TRANSFORM) != 0; \
+                note_launch<T>("fused_shs_kernel", LOG2D, K, (int)AX, (bool)EYE, (bool)NT, (int)BLK, (int)POL, (int)STG, shared_, one_); \
+                const dim3 grid_((unsigned)((n_tiles + (BLK / 64) - 1) / (BLK / 64)));                  \
+                if (shared_ && one_)                                                                    \
+                    hipLaunchKernelGGL((fused_shs_kernel<T, LOG2D, K, AX, EYE, NT, BLK, POL, STG, true, true>), grid_, dim3(BLK), smem_s, st, \
+                                       (u32x4 *)dst, (const u32x4 *)src, (const T *)a, (const T *)b, (const T *)c, n_chunks, n_tiles, ds, dn, dg, flags, same_sample_blocks); \
+                else if (shared_)                                                                       \
+                    hipLaunchKernelGGL((fused_shs_kernel<T, LOG2D, K, AX, EYE, NT, BLK, POL, STG, true, false>), grid_, dim3(BLK), smem_s, st, \
+                                       (u32x4 *)dst, (const u32x4 *)src, (const T *)a, (const T *)b, (const T *)c, n_chunks, n_tiles, ds, dn, dg, flags, same_sample_blocks); \
+                else                                                                                    \
+                    hipLaunchKernelGGL((fused_shs_kernel<T, LOG2D, K, AX, EYE, NT, BLK, POL, STG, false, true>), grid_, dim3(BLK), smem_s, st, \
+                                       (u32x4 *)dst, (const u32x4 *)src, (const T *)a, (const T *)b, (const T *)c, n_chunks, n_tiles, ds, dn, dg, flags, same_sample_blocks); \
                 break;                                                                                  \
             }                                                                                           \
         }                                                                                               \
@@ -514,7 +521,7 @@ inline void launch_fused(void *dst, const void *src, const void *a, const void *
     if (tune_env != nullptr) {
         use_nt = tune_env[2] != '0';
         const int want = tune_env[3] - '0';
-        if (want == STAGE_NONE || (want == STAGE_AC && ((flags & 3) == 0 || one_sample_blocks)) || (want == STAGE_ABC && one_sample_blocks)) {
+        if (want == STAGE_NONE || (want == STAGE_AC && ((flags & 3) == 0 || one_sample_blocks)) || (want == STAGE_ABC && one_sample_blocks && !(flags & (WHVI_FUSED_SRC_SHARED | WHVI_FUSED_ONE_TRANSFORM)))) {
             stage = want;
             same_sample_blocks = 0;
         }
@@ -581,8 +588,11 @@ inline int fused_dispatch(void *dst, const void *src, const void *a, const void 
     }
     if (axis != WHVI_AXIS_ROW && axis != WHVI_AXIS_COL)
         return fail(WHVI_ERR_ARG, "whvi: bad axis%s %lld", "", axis);
-    if (flags & ~(WHVI_FUSED_A_PER_SAMPLE | WHVI_FUSED_C_PER_SAMPLE | WHVI_FUSED_SRC_SHARED))
+    if (flags & ~(WHVI_FUSED_A_PER_SAMPLE | WHVI_FUSED_C_PER_SAMPLE | WHVI_FUSED_SRC_SHARED | WHVI_FUSED_ONE_TRANSFORM))
         return fail(WHVI_ERR_ARG, "whvi: unknown fused flags%s 0x%llx", "", flags);
+    if ((flags & WHVI_FUSED_ONE_TRANSFORM) && (src == nullptr || c != nullptr || axis != WHVI_AXIS_COL || log2d - LV < 6))
+        return fail(WHVI_ERR_ARG, "whvi: the one-transform flag needs axis = COL, src != NULL, c == NULL and rows of at least "
+                    "64 sixteen-byte chunks%s", "");
     if ((flags & WHVI_FUSED_SRC_SHARED) && (src == nullptr || dst == src || axis != WHVI_AXIS_COL || log2d - LV < 6))
         return fail(WHVI_ERR_ARG, "whvi: the shared-source flag needs axis = COL, src != NULL, dst != src and rows of at least "
                     "64 sixteen-byte chunks%s", "");

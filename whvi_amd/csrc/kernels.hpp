@@ -682,8 +682,11 @@ constexpr int STAGE_NONE = 0, STAGE_AC = 1, STAGE_ABC = 3;
 // SHARED_SRC (WHVI_FUSED_SRC_SHARED; AXIS_COL, rows of >= 64 chunks): src holds the rows of ONE sample -- sample_stride of
 // them -- shared by all samples, row r reads src row r mod sample_stride.  The (batch, D) input of a layer's first
 // Monte-Carlo pass is then read from the caches instead of being expanded to (S, batch, D) in HBM first.
+// ONE (WHVI_FUSED_ONE_TRANSFORM; c must be NULL): dst = a (.) FWHT(b_s (.) src) -- the second half of the pipeline alone.
+// With a shared source the first half, FWHT(c (.) x), is the same for every sample: it is computed ONCE (a ONE launch with
+// b := c) and every sample then costs one transform instead of two -- the same multiplies and butterflies, the same bits.
 template <typename T, int LOG2D, int K, int AXIS, bool EYE, bool NT, int BLOCK, int POLICY = POLICY_DPP,
-          int STAGE = STAGE_NONE, bool SHARED_SRC = false>
+          int STAGE = STAGE_NONE, bool SHARED_SRC = false, bool ONE = false>
 __global__ void __launch_bounds__(BLOCK)
 fused_shs_kernel(u32x4 *dst, const u32x4 *src, const T *a, const T *b, const T *c,
                  int64_t n_chunks, int64_t n_tiles, FastDiv by_sample_stride, FastDiv by_n_samples,
@@ -755,7 +758,7 @@ fused_shs_kernel(u32x4 *dst, const u32x4 *src, const T *a, const T *b, const T *
         const int64_t t_first = same_sample_blocks != 0u ? t - (int64_t)wave * by_n_samples.d : blk * (BLOCK / 64);   // wave 0's tile
         const uint32_t blk_row0 = (uint32_t)((t_first * TILE) >> SH);
         const size_t s_off = (size_t)sample_index(blk_row0) << LOG2D;
-        stg_src[0] = c == nullptr ? nullptr : c + (c_per_sample ? s_off : 0);
+        stg_src[0] = (c == nullptr || ONE) ? nullptr : c + (c_per_sample ? s_off : 0);
         stg_src[1] = a == nullptr ? nullptr : a + (a_per_sample ? s_off : 0);
         stg_src[2] = (STAGE == STAGE_ABC && b != nullptr) ? b + s_off : nullptr;
 #pragma unroll
@@ -829,7 +832,7 @@ fused_shs_kernel(u32x4 *dst, const u32x4 *src, const T *a, const T *b, const T *
 
     // The two transforms of the pipeline use the signed DPP form (fwht_tile.hpp): the first leaves the tile with
     // sigma = (-1)^popcount(lane & mask), the scalings between them commute with it, the second takes it back to 0.
-    constexpr bool SIGNED = WHVI_FUSED_SIGNED && POLICY == POLICY_DPP;
+    constexpr bool SIGNED = WHVI_FUSED_SIGNED && POLICY == POLICY_DPP && !ONE;   // (one transform alone: the unsigned network)
     constexpr int SIGN_MID = SIGNED ? fwht_sign_out<VEC, LOG2D>(0) : 0;
     static_assert(!SIGNED || fwht_sign_out<VEC, LOG2D>(SIGN_MID) == 0, "two transforms restore the sign convention");
     auto transform = [&](A (&r)[K][VEC], auto second) {
@@ -963,12 +966,14 @@ fused_shs_kernel(u32x4 *dst, const u32x4 *src, const T *a, const T *b, const T *
     } else {
 #pragma unroll
         for (int k = 0; k < K; ++k) E::unpack(raw[k], r[k]);
-        if (c != nullptr) {
-            if constexpr (STAGE != STAGE_NONE) apply_staged(lds_c);
-            else scale_chunkwise(c, c_per_sample);
+        if constexpr (!ONE) {
+            if (c != nullptr) {
+                if constexpr (STAGE != STAGE_NONE) apply_staged(lds_c);
+                else scale_chunkwise(c, c_per_sample);
+            }
         }
     }
-    transform(r, IC<0>{});
+    if constexpr (!ONE) transform(r, IC<0>{});
     if (b != nullptr) {
         if constexpr (STAGE == STAGE_ABC) apply_staged(lds_b);
         else scale_chunkwise(b, true);

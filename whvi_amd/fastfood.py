@@ -43,8 +43,11 @@ def _pipeline(x, a, b, c, n_samples, sample_stride, shared=False):
         if x.device.type == "cuda":
             from whvi_amd import _hip
             if _hip.fused_src_shared_supported(x.dtype, x.size(1)):
-                return _hip.fused_shs(x, a, b, c, axis="col", n_samples=n_samples, sample_stride=sample_stride,
-                                      src_shared=True)
+                # fwht(c * x) is the same for every sample: once, then ONE transform per sample on the shared result
+                # (the same multiplies and butterflies in the same order as the two-transform launch: the same bits)
+                t = _hip.fused_shs(x, None, c.reshape(1, -1), None, axis="col", n_samples=1, one_transform=True)
+                return _hip.fused_shs(t, a, b, None, axis="col", n_samples=n_samples, sample_stride=sample_stride,
+                                      src_shared=True, one_transform=True)
         x = x.repeat(n_samples, 1)
     if x.device.type == "cuda":
         from whvi_amd import _hip
