@@ -178,3 +178,36 @@ def test_random_weight_construction(case, dtype, J, S, D, R, mean, hip_lib):
         first = 1 if mean else 0
         for other in forms[1:]:
             assert torch.equal(other[:, :, first:, :R], forms[0][:, :, first:, :R]), case
+
+
+def _shared_cases():
+    rng = np.random.default_rng(404)
+    out = []
+    for i in range(max(16, N_CASES // 2)):
+        dtype = np.float64 if i % 3 == 2 else np.float32
+        log2d = int(rng.integers(8 if dtype == np.float32 else 7, 13))
+        S = int(rng.integers(1, 9))
+        B = int(rng.integers(1, 70)) * (32 if i % 4 == 0 else 1)            # some batches whole blocks, most ragged
+        out.append((i, dtype, log2d, S, B, bool(i % 2)))
+    return out
+
+
+@pytest.mark.parametrize("case,dtype,log2d,S,B,one", _shared_cases())
+def test_random_shared_source(case, dtype, log2d, S, B, one, hip_lib):
+    """WHVI_FUSED_SRC_SHARED (a (batch, D) source read by every sample) and WHVI_FUSED_ONE_TRANSFORM (the second half of
+    the pipeline alone) on random shapes, bit for bit against ``oracle.pipeline`` on the expanded input."""
+    d = 1 << log2d
+    if S * B * d > (1 << 25):
+        B = max(1, (1 << 25) // (S * d))
+    rng = np.random.default_rng(3000 + case)
+    x = rng.standard_normal((B, d)).astype(dtype)
+    a, c = rng.standard_normal(d).astype(dtype), rng.standard_normal(d).astype(dtype)
+    b = rng.standard_normal((S, d)).astype(dtype)
+    t = lambda v: torch.from_numpy(v).to(DEV)   # noqa: E731
+    want = oracle.pipeline(np.tile(x, (S, 1)), a, b, c, n_samples=S, sample_stride=B, axis="col")
+    if one:
+        first = _hip.fused_shs(t(x), None, t(c).reshape(1, -1), None, axis="col", n_samples=1, one_transform=True)
+        got = _hip.fused_shs(first, t(a), t(b), None, axis="col", n_samples=S, sample_stride=B, src_shared=True, one_transform=True)
+    else:
+        got = _hip.fused_shs(t(x), t(a), t(b), t(c), axis="col", n_samples=S, sample_stride=B, src_shared=True)
+    assert np.array_equal(got.cpu().numpy().view(np.uint8), want.view(np.uint8)), (case, dtype, log2d, S, B, one)
