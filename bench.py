@@ -311,6 +311,21 @@ def _extra_sweep(device):
     return out
 
 
+def _extra_copy_reference(device):
+    """Context for the roofline fractions: what the SAME HBM gives two memory-bound operations that compute nothing -- the
+    vendor's device-to-device copy (``Tensor.copy_``, 4 GiB read + 4 GiB written) and torch's in-place elementwise kernel on
+    a 4 GiB buffer (read + write of the same addresses, the transform's access pattern)."""
+    x = torch.randn(1 << 30, device=device)
+    y = torch.empty_like(x)
+    copy_ms = event_ms(lambda: y.copy_(x), iters=10, warm=3)
+    inplace_ms = event_ms(lambda: x.mul_(1.0), iters=10, warm=3)
+    gb = 2 * x.numel() * 4 / 1e6
+    return {"copy_4GiB_out_of_place_GB_per_s": round(gb / copy_ms, 1), "copy_frac_of_peak": round(gb / copy_ms / HBM_PEAK_GBS, 4),
+            "torch_inplace_elementwise_4GiB_GB_per_s": round(gb / inplace_ms, 1),
+            "torch_inplace_frac_of_peak": round(gb / inplace_ms / HBM_PEAK_GBS, 4),
+            "note": "bytes counted as read + written, like the transform's algorithmic bytes"}
+
+
 def _extra_long_rows(device):
     """Rows beyond one wavefront tile (outside the metric's D range): one block of 4 / 8 / 16 waves per row, one pass,
     4 GiB in place; every launch is followed by an untimed rescale that brings the values back to where they started."""
@@ -583,7 +598,8 @@ def extras(device):
     """Secondary measurements (inputs resident, HIP-event timed).  Every section is independent: a failure is
     recorded under its own key and never costs the other numbers or the headline line."""
     out = {}
-    for key, fn in (("fwht_f32_sweep_4GiB", _extra_sweep), ("fwht_long_rows_4GiB", _extra_long_rows),
+    for key, fn in (("fwht_f32_sweep_4GiB", _extra_sweep), ("hbm_copy_reference", _extra_copy_reference),
+                    ("fwht_long_rows_4GiB", _extra_long_rows),
                     ("fwht_f16_D4096_2^20rows", _extra_f16),
                     ("fused_shs_D2048_S64_B8192", _extra_fused), ("fastfood_module_D2048_S64_B8192", _extra_fastfood),
                     ("wbar_fwd", _extra_wbar_fwd),
