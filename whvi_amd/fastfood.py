@@ -59,6 +59,22 @@ def _pipeline(x, a, b, c, n_samples, sample_stride, shared=False):
     return a * _fwht(b[rows] * _fwht(c * x))
 
 
+def _scale_fwht(x, vec, n_samples=1, sample_stride=1):
+    """``fwht(vec[s(r)] * x[r])`` for every row -- ``vec`` of shape ``(D,)`` (shared) or ``(n_samples, D)`` with
+    s(r) = (r // sample_stride) % n_samples -- as one launch of the fused kernel's one-transform form on the GPU."""
+    per_sample = vec.dim() == 2
+    if x.device.type == "cuda":
+        from whvi_amd import _hip
+        if _hip.fused_src_shared_supported(x.dtype, x.size(1)):
+            return _hip.fused_shs(x, None, vec if per_sample else vec.reshape(1, -1), None, axis="col",
+                                  n_samples=n_samples if per_sample else 1, sample_stride=sample_stride if per_sample else 1,
+                                  one_transform=True)
+    if per_sample:
+        rows = torch.arange(x.size(0), device=x.device) // sample_stride % n_samples
+        return _fwht(vec[rows] * x)
+    return _fwht(vec * x)
+
+
 class FastfoodFunction(torch.autograd.Function):
     """``y = a * fwht(b_s * fwht(c * x))`` on rows ``(n_samples, rows_per_sample, D)`` flattened, ``b``: (S, D).
 
@@ -90,20 +106,22 @@ class FastfoodFunction(torch.autograd.Function):
             fold = lambda g: g                                                        # noqa: E731
         if need_x and not (need_a or need_b or need_c):
             return fold(_pipeline(grad_y, c, b, a, S, stride)), None, None, None, None, None, None
-        rows = torch.arange(x.size(0), device=x.device) // stride % S
-        b_rows = b[rows]
-        t1 = _fwht(c * x)                                   # forward intermediates, recomputed
+        # Every transform of the backward pass is "scale, then FWHT" (optionally scaled again): ONE launch each through the
+        # one-transform form of the fused kernel where it exists, the multiply + plain transform elsewhere -- the same
+        # roundings either way (tests/test_streaming_parity_gpu.py pins the launch to multiply + fwht_rows bit for bit)
+        t1 = _scale_fwht(x, c)                              # forward intermediate fwht(c * x), recomputed
         if need_a:
-            grad_a = (grad_y * _fwht(b_rows * t1)).sum(dim=0)
-        v = _fwht(a * grad_y)                               # gradient at (b * t1)
+            grad_a = (grad_y * _scale_fwht(t1, b, S, stride)).sum(dim=0)
+        v = _scale_fwht(grad_y, a)                          # gradient at (b * t1)
         if need_b:
             prod = v * t1
             if stride * S == x.size(0):                     # (S, rows_per_sample, D) layout: one segmented sum
                 grad_b = prod.view(S, stride, -1).sum(dim=1)
             else:
+                rows = torch.arange(x.size(0), device=x.device) // stride % S
                 grad_b = torch.zeros_like(b).index_add_(0, rows, prod)
         if need_c or need_x:
-            w = _fwht(b_rows * v)                           # gradient at (c * x)
+            w = _scale_fwht(v, b, S, stride)                # gradient at (c * x)
             if need_c:
                 grad_c = (w * x).sum(dim=0)
             if need_x:
