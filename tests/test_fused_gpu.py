@@ -957,3 +957,32 @@ def test_one_launch_mean_plus_sample_weights_equal_the_two_launch_form(dtype, J,
     with pytest.raises(RuntimeError, match="two-launch form only"):
         _hip.wbar_fwd_mean(torch.zeros(1, long_d, dtype=dtype, device=DEV), torch.zeros(1, 2, long_d, dtype=dtype, device=DEV),
                            torch.zeros(1, long_d, dtype=dtype, device=DEV), 1, inline=True)
+
+
+@pytest.mark.parametrize("key", ["f32_D64", "f32_D512", "f32_D2048", "f64_D64", "f64_D512"])
+def test_column_pipeline_vs_vectors_recorded_from_the_reference_gpu(key, hip_lib):
+    """``whvi_fused_shs_*`` (axis = COL) straight against vectors the LIVE reference composed from its own
+    ``matmul_diag_right`` and FWHT function (tests/golden/pipeline_golden.npz, make_golden_r3.py) -- no oracle in between:
+    shared and per-sample outer vectors, both row orders, the one-transform half, bit for bit."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pipeline_golden.npz"))
+    x, s1, s2, gk = (g[f"{key}/{n}"] for n in ("x", "s1", "s2", "g"))
+    S, B = gk.shape[0], x.shape[0] // gk.shape[0]
+    bits = lambda v: v.view(np.uint8)   # noqa: E731
+    for order, stride in (("batch", 1), ("sample", B)):
+        kw = dict(axis="col", n_samples=S, sample_stride=stride)
+        got = _hip.fused_shs(_t(x), _t(s1[0]), _t(gk), _t(s2[0]), **kw).cpu().numpy()
+        assert np.array_equal(bits(got), bits(g[f"{key}/{order}/shared"])), (key, order)
+        got = _hip.fused_shs(_t(x), _t(s1), _t(gk), _t(s2), a_per_sample=True, c_per_sample=True, **kw).cpu().numpy()
+        assert np.array_equal(bits(got), bits(g[f"{key}/{order}/per_sample"])), (key, order)
+        if _hip.fused_src_shared_supported(torch.from_numpy(x).dtype, x.shape[1]):
+            got = _hip.fused_shs(_t(x), _t(s1[0]), _t(gk), None, one_transform=True, **kw).cpu().numpy()
+            assert np.array_equal(bits(got), bits(g[f"{key}/{order}/one_transform"])), (key, order)
+
+
+def test_integer_wrap_vectors_recorded_from_the_reference_gpu(hip_lib):
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pipeline_golden.npz"))
+    for D in (64, 4096):
+        got = _hip.fwht_rows(_t(g[f"wrap_i32_D{D}/in"])).cpu().numpy()
+        assert np.array_equal(got, g[f"wrap_i32_D{D}/out"]), D

@@ -230,3 +230,36 @@ def test_sample_and_w_bar_vs_reference():
                                          ((8, 8), (8, 8, 0, 1)), ((4, 6), (4, 8, 0, 2))])
 def test_setup_dimensions_probes(args, expect):
     assert wo.setup_dimensions(*args) == expect   # values probed on the reference
+
+
+def _pipeline_golden():
+    return np.load(os.path.join(GOLD, "pipeline_golden.npz"))
+
+
+@pytest.mark.parametrize("key", ["f32_D64", "f32_D512", "f32_D2048", "f64_D64", "f64_D512"])
+def test_column_pipeline_vs_vectors_recorded_from_the_reference(key):
+    """The column-scaling pipeline (BASELINE config 3's dataflow) against vectors composed by the LIVE reference from its
+    own ``matmul_diag_right`` (src/utils.py:15-23) and FWHT function (src/fwht/cpp/fwht.py:7-18) --
+    tests/golden/make_golden_r3.py: shared and per-sample outer vectors, both row orders, and the one-transform half,
+    bit for bit.  This is what pins ``oracle.pipeline(axis="col")`` -- the checker of every fused-kernel GPU test --
+    to the reference's code rather than to the oracle's own composition."""
+    g = _pipeline_golden()
+    x, s1, s2, gk = (g[f"{key}/{n}"] for n in ("x", "s1", "s2", "g"))
+    S, B = gk.shape[0], x.shape[0] // gk.shape[0]
+    for order, stride in (("batch", 1), ("sample", B)):
+        kw = dict(n_samples=S, sample_stride=stride, axis="col")
+        got = oracle.pipeline(x, s1[0], gk, s2[0], **kw)
+        assert np.array_equal(got.view(np.uint8), g[f"{key}/{order}/shared"].view(np.uint8)), (key, order)
+        got = oracle.pipeline(x, s1, gk, s2, a_per_sample=True, c_per_sample=True, **kw)
+        assert np.array_equal(got.view(np.uint8), g[f"{key}/{order}/per_sample"].view(np.uint8)), (key, order)
+        # the one-transform half a * fwht(b * x): the oracle's plain transform between two multiplies
+        smp = (np.arange(x.shape[0]) // stride) % S
+        half = (s1[0] * oracle.fwht((gk[smp] * x).astype(x.dtype))).astype(x.dtype)
+        assert np.array_equal(half.view(np.uint8), g[f"{key}/{order}/one_transform"].view(np.uint8)), (key, order)
+
+
+def test_integer_wrap_vectors_recorded_from_the_reference():
+    g = _pipeline_golden()
+    for D in (64, 4096):
+        for kind in ("i32", "i64"):
+            assert np.array_equal(oracle.fwht(g[f"wrap_{kind}_D{D}/in"]), g[f"wrap_{kind}_D{D}/out"]), (kind, D)
