@@ -75,6 +75,26 @@ def test_argument_checks_without_gpu():
     assert [L.whvi_max_log2d(i) for i in range(5)] == [24, 24, 16, 24, 16] and L.whvi_max_log2d(7) == -1
 
 
+def test_argument_checks_of_the_fused_flags_without_gpu():
+    """WHVI_FUSED_SRC_SHARED / WHVI_FUSED_ONE_TRANSFORM: the conditions include/whvi_hip.h states are checked before any
+    launch -- an unknown flag, a shared source in place, a one-transform call with c, rows shorter than 1 KiB, the row
+    axis -- and say which flag they are about."""
+    from whvi_amd import _hip
+    L = _hip.lib()
+    buf = (ctypes.c_char * 65536)()
+    p = (ctypes.addressof(buf) + 15) & ~15
+    q = p + 32768
+    fused = L.whvi_fused_shs_ex_f32
+    assert fused(q, p, None, None, None, 4, 9, 2, 2, 1, 1, 16, None) == -1 and "unknown fused flags" in _hip.last_error()
+    assert fused(p, p, None, None, None, 4, 9, 2, 2, 1, 1, 4, None) == -5 and "shared source" in _hip.last_error()   # in place
+    assert fused(q, p, None, None, None, 4, 9, 2, 2, 1, 0, 4, None) == -1                                            # row axis
+    assert fused(q, p, None, None, None, 4, 7, 2, 2, 1, 1, 4, None) == -1                                            # 512-byte rows
+    assert fused(q, p, None, None, p, 4, 9, 2, 2, 1, 1, 8, None) == -1 and "one-transform" in _hip.last_error()      # c given
+    assert fused(q, None, None, None, None, 4, 9, 2, 2, 1, 1, 8, None) == -1                                         # no source
+    assert L.whvi_fused_shs_ex_f64(q, p, None, None, None, 4, 6, 2, 2, 1, 1, 8, None) == -1                          # f64: 512-byte rows
+    assert fused(q, p, None, None, None, 0, 9, 2, 2, 1, 1, 12, None) == 0                                            # empty batch
+
+
 def test_argument_checks_of_the_training_step_entry_points():
     """whvi_wbar_fwd / _bwd, whvi_reparam_kl_bwd, whvi_gauss_mnll: bad arguments are reported before any launch."""
     from whvi_amd import _hip
