@@ -235,11 +235,11 @@ __device__ __forceinline__ u32x4 uniform_ld16(const void *base, uint32_t bytes, 
     return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, byte_offset, NT ? (1 << 1) : WHVI_VEC_AUX));
 }
 // the store counterpart; writes beyond `bytes` are dropped.  NT: write-through + non-temporal (see tile_store_stream)
-template <bool NT>
+template <bool NT, bool WRITE_THROUGH = true>
 __device__ __forceinline__ void uniform_st16(void *base, uint32_t bytes, int lane, int byte_offset, const u32x4 &v)
 {
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)bytes, 0x00020000);
-    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, lane * 16, byte_offset, NT ? ((1 << 4) | (1 << 1)) : 0);
+    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, lane * 16, byte_offset, NT ? ((WRITE_THROUGH ? (1 << 4) : 0) | (1 << 1)) : 0);
 }
 
 // ---- batched row FWHT ------------------------------------------------------------------------
@@ -985,7 +985,7 @@ fused_shs_kernel(u32x4 *dst, const u32x4 *src, const T *a, const T *b, const T *
     }
     if constexpr (NT) __syncthreads();          // the block's 4 waves write their 64 KiB back together
 #pragma unroll
-    for (int k = 0; k < K; ++k) uniform_st16<NT>(dst + base, tile_bytes, lane, k * 1024, E::pack(r[k]));
+    for (int k = 0; k < K; ++k) uniform_st16<NT, !(SHARED_SRC && WHVI_FUSED_SHARED_PLAIN_NT)>(dst + base, tile_bytes, lane, k * 1024, E::pack(r[k]));
 }
 
 // Rows shorter than one 16-byte chunk (D = 1, 2 for f32; D = 1 for f64): one thread per row, same

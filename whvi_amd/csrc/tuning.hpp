@@ -14,7 +14,7 @@
 #define WHVI_TUNE_ENV(name) ((const char *)nullptr)
 #if defined(WHVI_F16_UNPACK) || defined(WHVI_F16_PACK_EXP) || defined(WHVI_BF16_PACK) || defined(WHVI_ROWS_WAVES_PER_EU) || \
     defined(WHVI_ROWS_PKMASK) || defined(WHVI_FUSED_PKMASK) || defined(WHVI_FUSED_SIGNED) || defined(WHVI_EXP_UNFUSED_DPP) || \
-    defined(WHVI_NO_PK) || defined(WHVI_BLOCK_TRACE) || defined(WHVI_VEC_AUX) || defined(WHVI_FUSED_UPFRONT_8THS) || defined(WHVI_ROWS_BUFFER_IO) || defined(WHVI_FUSED_TILE_LOADS) || defined(WHVI_F64_STREAM_FORM)
+    defined(WHVI_NO_PK) || defined(WHVI_BLOCK_TRACE) || defined(WHVI_VEC_AUX) || defined(WHVI_FUSED_UPFRONT_8THS) || defined(WHVI_ROWS_BUFFER_IO) || defined(WHVI_FUSED_TILE_LOADS) || defined(WHVI_F64_STREAM_FORM) || defined(WHVI_FUSED_SHARED_PLAIN_NT) || defined(WHVI_WBAR_FWD_STORE)
 #error "kernel tuning switches need -DWHVI_TUNING_BUILD (make -C whvi_amd/csrc tuning DEFS=-D...)"
 #endif
 #endif
@@ -54,4 +54,8 @@
 #define WHVI_F64_STREAM_FORM 2     // f64 streams of 64-register tiles: 2 = 256-thread blocks + store barrier + signed (fma) DPP network
                                    // (production), 0 = 1024-thread blocks (round 2), 1 = 256 + barrier, unsigned; 3 = as 2 and
                                    // the signed network for 128-register tiles (D = 4096) too
+#endif
+#ifndef WHVI_FUSED_SHARED_PLAIN_NT
+#define WHVI_FUSED_SHARED_PLAIN_NT 1   // fused kernel on a shared (cache-resident) source = a write-dominated stream: non-temporal
+                                       // stores without the write-through bit (0: the sc1 nt stores of the read + write streams)
 #endif

@@ -116,9 +116,22 @@ wbar_fwd_kernel(u32x4 *dst, const T *s1, const T *u, const T *s2, const u32x4 *b
         }
     }
     if constexpr (NT) __syncthreads();
-    if (NT && full) {
+    // A WRITE-ONLY stream: plain non-temporal global stores.  The write-through (sc1) buffer stores that win on the read +
+    // write streams of the transform kernels (+3 % there) LOSE here: 6.35 vs 6.80 TB/s at D = 2048 x 256 (4 GiB), 6.41 vs
+    // 6.85 at D = 512 x 2048, 6.92 vs 7.25 at D = 4096 x 32; a tie at 1 GiB (6.60 vs 6.53) -- measurement builds
+    // -DWHVI_WBAR_FWD_STORE=0|1 (0: sc1 nt buffer stores, 1: cached stores), tools/probe_wbar_fwd_stream.py,
+    // profiles/r03/write_stream_store_form_ab.log.  torch's fill on the same 4 GiB: 6.93 TB/s.
+#if defined(WHVI_TUNING_BUILD) && defined(WHVI_WBAR_FWD_STORE)
+    constexpr int STORE_FORM = WHVI_WBAR_FWD_STORE;
+#else
+    constexpr int STORE_FORM = 2;
+#endif
+    if (NT && full && STORE_FORM == 0) {
 #pragma unroll
         for (int k = 0; k < K; ++k) tile_store_stream(dst + tile0, lane, k, E::pack(r[k]), TILE * 16);
+    } else if (NT && full) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) st16<(STORE_FORM == 2)>(dst + tile0 + k * 64 + lane, E::pack(r[k]));
     } else {
 #pragma unroll
         for (int k = 0; k < K; ++k)
