@@ -582,12 +582,14 @@ def test_weight_construction_at_streaming_size(D, S, hip_lib):
 
 
 @pytest.mark.gpu
-def test_graphed_training_with_a_ragged_last_batch(hip_lib):
+@pytest.mark.parametrize("max_shapes", [1, 2])
+def test_graphed_training_with_a_ragged_last_batch(max_shapes, hip_lib):
     """``train_model(graphed=True)`` on a data set whose last batch is short (20 rows in batches of 8: 8, 8, 4): the full
-    batches are hipGraph replays, the short one takes the eager step BESIDE the captured one -- detached from the graph's
-    static gradient buffers first, or its backward would accumulate into what the last replay left there.  Same generator
-    seed -> the run equals the all-eager run of the same recipe (same draws in the same order), every step counted by the
-    device-resident schedule."""
+    batches are hipGraph replays; the short one is a second captured step sharing the optimizer state and the schedule
+    (``max_shapes=2``, the default) or takes the eager step BESIDE the captured one (``max_shapes=1``) -- detached from the
+    graph's static gradient buffers first, or its backward would accumulate into what the last replay left there.  Same
+    generator seed -> the run equals the all-eager run of the same recipe (same draws in the same order), every step
+    counted by the device-resident schedule.  A second ``train_model`` call continues on the same captured steps."""
     import copy
     torch.manual_seed(8)
     net = WHVIRegression([WHVILinear(3, 16, lambda_=2.0), nn.ReLU(), WHVILinear(16, 16, lambda_=2.0), nn.ReLU(),
@@ -598,10 +600,47 @@ def test_graphed_training_with_a_ragged_last_batch(hip_lib):
     opt, sched = make_optimizer(net, lambda0=0.05, capturable=True)
     opt2, sched2 = make_optimizer(twin, lambda0=0.05, capturable=True)
     torch.manual_seed(77)
-    step = net.train_model(loader, opt, sched, epochs1=2, epochs2=2, graphed=True)
+    step = net.train_model(loader, opt, sched, epochs1=2, epochs2=2, graphed=True, graph_options={"max_shapes": max_shapes})
     assert step is not None and float(sched.t) == 12.0                     # 4 epochs x 3 batches, replayed or eager
+    assert len(net._train_graphs["steps"]) == max_shapes and tuple(step.static_x.shape) == (8, 3)
     torch.manual_seed(77)
     twin.train_model(loader, opt2, sched2, epochs1=2, epochs2=2)           # the same recipe, all eager
     assert float(sched2.t) == 12.0 and abs(sched.get_last_lr()[0] - sched2.get_last_lr()[0]) < 1e-12
     for (k, a), (_, b) in zip(net.named_parameters(), twin.named_parameters()):
         assert bool(torch.isfinite(a).all()) and torch.allclose(a, b, rtol=1e-4, atol=1e-6), k
+    # a later call with the same optimizer / schedule / loader replays the SAME captured steps (no re-capture)
+    torch.manual_seed(78)
+    again = net.train_model(loader, opt, sched, epochs1=0, epochs2=1, graphed=True, graph_options={"max_shapes": max_shapes})
+    assert again is step and len(net._train_graphs["steps"]) == max_shapes and float(sched.t) == 15.0
+    torch.manual_seed(78)
+    twin.train_model(loader, opt2, sched2, epochs1=0, epochs2=1)
+    for (k, a), (_, b) in zip(net.named_parameters(), twin.named_parameters()):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-6), k
+
+
+@pytest.mark.gpu
+def test_evaluation_harness_fast_path_equals_the_reference_flow(tmp_path, hip_lib):
+    """``evaluate_bayesian_regression_dnn`` (src/evaluation.py:30-108) on the GPU: the fast path (packed parameters,
+    device-resident Adam + schedule, one hipGraph replay per step incl. the short last batch, ``DeviceBatches``) against
+    the reference's flow (DataLoader, host-side schedule, eager steps) from the same numpy / torch seeds -- same splits,
+    same draws in the same order, hence the same test error and test MNLL per split up to float32 reassociation in the
+    packed Adam update, and the same checkpoints under the reference's keys."""
+    import numpy as np
+    from whvi_amd.evaluation import evaluate_bayesian_regression_dnn
+    rng = np.random.default_rng(11)
+    X = rng.normal(size=(150, 6)).astype(np.float32) * 3 - 1
+    y = (np.sin(X[:, :1]) + 0.5 * X[:, 1:2] + 0.05 * rng.normal(size=(150, 1))).astype(np.float32)
+    kwargs = dict(epochs1=2, epochs2=6, n_splits=2, batch_size=64, hidden=32, eval_samples=16,
+                  optimizer_kwargs={"lambda0": 0.03})             # effective rate 9e-4: the parameters move
+    results = {}
+    for fast in (False, True):
+        np.random.seed(4)
+        torch.manual_seed(4)
+        results[fast] = evaluate_bayesian_regression_dnn(X, y, "cuda", tmp_path / str(fast), fast=fast, **kwargs)
+    assert all(np.isfinite(v) for v in results[True])
+    assert np.allclose(results[True], results[False], rtol=2e-4, atol=1e-6), results
+    slow = torch.load(tmp_path / "False" / "iter-1" / "epoch-0.pth")          # written after the first epoch of phase two
+    quick = torch.load(tmp_path / "True" / "iter-1" / "epoch-0.pth")
+    assert list(quick.keys()) == list(slow.keys())
+    for k in quick:
+        assert torch.allclose(quick[k], slow[k], rtol=1e-4, atol=1e-6), k

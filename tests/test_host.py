@@ -361,6 +361,8 @@ def test_src_alias_package_matches_reference_import_paths():
     for mod, names in (("src.utils", ["matmul_diag_left", "matmul_diag_right", "kl_diag_normal", "build_H", "is_pow_of_2"]),
                        ("src.weights", ["WHVISquarePow2Matrix", "WHVIStackedMatrix", "WHVIColumnMatrix"]),
                        ("src.likelihoods", ["GaussianLikelihood", "Likelihood"]),
+                       ("src.activations", ["Cosine"]),
+                       ("src.evaluation", ["make_optimizer", "evaluate_bayesian_regression_dnn"]),
                        ("src.fwht.cpp.fwht", ["FWHTFunction", "FWHT"]), ("src.fwht.cuda.fwht", ["FWHTFunction"]),
                        ("src.fwht.python.fwht", ["FWHTFunction", "WHT_matmul", "FWHT"])):
         m = importlib.import_module(mod)
@@ -474,3 +476,63 @@ def test_fast_training_path_refuses_the_host_clearly(tmp_path):
     opt3, sched3 = make_optimizer(third, packed=True)
     assert len(list(third.parameters())) < len(keys) and list(third.state_dict().keys()) == keys
     third.train_model(loader, opt3, sched3, epochs1=1, epochs2=0, packed=True)
+
+
+def test_evaluation_harness_protocol_on_the_host(tmp_path, capsys):
+    """``evaluate_bayesian_regression_dnn`` (src/evaluation.py:30-108) with the reference's flow (``fast=False``: DataLoader,
+    host Adam + LambdaLR): standardised inputs, 90 / 10 splits, the (n_in, hidden, hidden, n_out) network with lambda_ = 3
+    on the hidden layers, per-split checkpoint directories holding the reference's keys, four floats back.  The same
+    numpy / torch seeds give the same numbers; a manual composition of the same pieces for split 0 reproduces its error and
+    MNLL exactly (the function IS that composition)."""
+    from sklearn.model_selection import train_test_split
+    from sklearn.preprocessing import StandardScaler
+    from torch.utils.data import DataLoader, TensorDataset
+    from whvi_amd.activations import Cosine
+    from whvi_amd.evaluation import DeviceBatches, evaluate_bayesian_regression_dnn, make_optimizer
+    rng = np.random.default_rng(3)
+    X = rng.normal(size=(50, 5)).astype(np.float32) * 4 + 2
+    y = (X[:, :2].sum(axis=1, keepdims=True) + 0.1 * rng.normal(size=(50, 1))).astype(np.float32)
+    kwargs = dict(epochs1=1, epochs2=2, n_splits=2, batch_size=16, hidden=16, eval_samples=8, fast=False)
+
+    def run(where):
+        np.random.seed(0)
+        torch.manual_seed(0)
+        return evaluate_bayesian_regression_dnn(X, y, "cpu", where, **kwargs)
+    first, second = run(tmp_path / "a"), run(tmp_path / "b")
+    assert first == second and len(first) == 4 and all(np.isfinite(v) for v in first)
+    out = capsys.readouterr().out
+    assert "Iteration 1/2" in out and "Iteration 2/2" in out and out.count("Error:") == 4
+    state = torch.load(tmp_path / "a" / "iter-1" / "epoch-0.pth")
+    assert "likelihood.sigma" in state and "sequential.2.weight_submodule.s1" in state
+    assert state["sequential.0.weight_submodule.weight_matrices.0.g_rho"].shape == (8,)       # (5 -> 16): two 8 x 8 blocks
+    with pytest.raises(RuntimeError, match="needs a GPU"):
+        evaluate_bayesian_regression_dnn(X, y, "cpu", tmp_path / "c", fast=True)
+    # split 0 by hand
+    np.random.seed(0)
+    torch.manual_seed(0)
+    Xs = StandardScaler().fit_transform(X)
+    X_train, X_test, y_train, y_test = train_test_split(Xs, y, train_size=0.9, test_size=0.1)
+    loader = DataLoader(TensorDataset(torch.tensor(X_train), torch.tensor(y_train)), batch_size=16)
+    model = WHVIRegression([WHVILinear(5, 16, lambda_=3.0), nn.ReLU(), WHVILinear(16, 16, lambda_=3.0), nn.ReLU(),
+                            WHVILinear(16, 1)], eval_samples=8)
+    optimizer, scheduler = make_optimizer(model)
+    model.train_model(loader, optimizer, scheduler, epochs1=1, epochs2=2, pbar_update_period=1)
+    error0, mnll0 = model.eval_model(torch.tensor(X_test), torch.tensor(y_test))
+    line = [ln for ln in out.splitlines() if ln.startswith("Error:")][0]
+    assert line == f"Error: {error0}, MNLL: {mnll0}"
+    # DeviceBatches == the DataLoader's batches (order, ragged tail, len(dataset))
+    Xt, yt = torch.tensor(X_train), torch.tensor(y_train)
+    views = DeviceBatches(Xt, yt, batch_size=16)
+    assert len(views) == len(loader) == 3 and len(views.dataset) == len(loader.dataset) == 45
+    for (a, b), (c, d) in zip(views, loader):
+        assert torch.equal(a, c) and torch.equal(b, d)
+    torch.manual_seed(9)                                                   # one pass consumes the host generator alike
+    list(views)
+    after_views = torch.rand(3)
+    torch.manual_seed(9)
+    list(loader)
+    assert torch.equal(after_views, torch.rand(3))
+    assert [tuple(a.shape) for a, _ in views] == [(16, 5), (16, 5), (13, 5)]
+    with pytest.raises(ValueError):
+        DeviceBatches(Xt, yt[:-1])
+    assert torch.equal(Cosine()(Xt), torch.cos(Xt))

@@ -1,13 +1,17 @@
-"""Optimizer set-up of the reference's experiment harness (src/evaluation.py:15-27).
-
-Only ``make_optimizer`` is mirrored: it is part of the training path.  The UCI experiment driver
-around it (``evaluate_bayesian_regression_dnn``: sklearn splits, dataset standardisation, eight repetitions) is a
-script over this package's public surface and out of scope.
+"""The reference's experiment harness (src/evaluation.py): ``make_optimizer`` (:15-27, part of the training path, SURVEY.md
+F4) and ``evaluate_bayesian_regression_dnn`` (:30-108), the caller of ``train_model`` / ``eval_model`` that the UCI
+regression scripts run (experiments/regression_experiments/run_*.py) -- the same protocol, with the training loop on the
+fast path (packed parameters, device-resident Adam + schedule, one hipGraph replay per step, batches sliced on the
+device) when the device is a GPU.  The data sets themselves are not part of this repo (no network; the scripts download
+them or read ``../datasets``).
 """
+import pathlib
+
 import torch
+import torch.nn as nn
 import torch.optim as optim
 
-__all__ = ["make_optimizer", "DeviceLambdaLR"]
+__all__ = ["make_optimizer", "DeviceLambdaLR", "DeviceBatches", "evaluate_bayesian_regression_dnn"]
 
 
 class DeviceLambdaLR:
@@ -94,3 +98,107 @@ def make_optimizer(net, gamma=0.0005, p=0.3, lambda0=0.001, capturable=False, pa
     optimizer = optim.Adam(net.parameters(), lr=torch.tensor(lambda0, dtype=torch.float32, device=device), capturable=True)
     scheduler = DeviceLambdaLR(optimizer, lambda t: lambda0 * torch.pow(1.0 + gamma * t, -p), base_lrs=[lambda0])
     return optimizer, scheduler
+
+
+class DeviceBatches:
+    """The batches ``DataLoader(TensorDataset(X, y), batch_size=b)`` yields -- in order, the last one short, exactly what
+    the reference's harness trains on (src/evaluation.py:73-74: no shuffling) -- as VIEWS of the two tensors.
+
+    Why: with the step itself a 0.3 ms hipGraph replay, ``DataLoader`` is the bottleneck by an order of magnitude (it
+    indexes the data set row by row and collates 64 one-row tensors per batch, on the device: ~130 tiny launches).  The
+    views are made once; ``train_model`` only needs iteration and ``len(loader.dataset)``."""
+
+    def __init__(self, X: torch.Tensor, y: torch.Tensor, batch_size: int = 64):
+        if X.size(0) != y.size(0):
+            raise ValueError("DeviceBatches: X and y differ in their number of rows")
+        from torch.utils.data import TensorDataset
+        self.dataset = TensorDataset(X, y)
+        self.batch_size = int(batch_size)
+        self._batches = [(X[i:i + self.batch_size], y[i:i + self.batch_size]) for i in range(0, X.size(0), self.batch_size)]
+
+    def __iter__(self):
+        # DataLoader's iterator draws its base seed from the host generator once per pass (torch/utils/data/dataloader.py,
+        # _BaseDataLoaderIter.__init__); the same draw here, so that whatever runs after the loop -- the next split's
+        # parameter initialisation in the harness below -- sees the same generator state under either loader
+        torch.empty((), dtype=torch.int64).random_()
+        return iter(self._batches)
+
+    def __len__(self):
+        return len(self._batches)
+
+
+def evaluate_bayesian_regression_dnn(X, y, device, checkpoint_dir, *, epochs1: int = 500, epochs2: int = 50000,
+                                     n_splits: int = 8, batch_size: int = 64, hidden: int = 128, eval_samples: int = 64,
+                                     fast=None, pbar_update_period=None, random_state=None, optimizer_kwargs=None):
+    """Test error (RMSE of the predictive mean) and test MNLL on the data set ``(X, y)``: the protocol of
+    src/evaluation.py:30-108 (section 3.2 of the paper, D.1 of its supplement), returned as ``(error_mean, error_sd,
+    mnll_mean, mnll_sd)`` over the random splits.
+
+    As in the reference: network ``(n_in, 128, 128, n_out)`` of ``WHVILinear`` layers with ``lambda_=3.0`` on the two
+    hidden ones and ReLU between, 64 MC samples at test time and 1 in training; columns of ``X`` standardised here
+    (over the WHOLE data set, before splitting -- as written in the reference), targets unchanged; eight random 90 % /
+    10 % splits (``sklearn.model_selection.train_test_split`` on numpy's global generator unless ``random_state`` is
+    given); ``make_optimizer`` defaults (Adam, lambda0 = 0.001 -- entering squared, p = 0.3, gamma = 0.0005); batches of
+    64 in data order; 500 epochs with the two-phase labels of ``train_model`` and 50 000 more, a checkpoint of the second
+    phase every 5 000 epochs under ``checkpoint_dir/iter-{k}/epoch-{e}.pth``.
+
+    The keyword arguments are not in the reference (its values are the defaults): ``epochs1`` / ``epochs2`` /
+    ``n_splits`` / ``batch_size`` / ``hidden`` / ``eval_samples`` for smaller runs; ``fast`` -- ``None`` = on a GPU --
+    selects ``make_optimizer(capturable=True, packed=True)``, ``train_model(graphed=True)`` and ``DeviceBatches``: the same
+    arithmetic per step (tests/test_config_parity.py::test_evaluation_harness_fast_path_equals_the_reference_flow), the
+    308-row yacht data set's 252 500 steps per split in minutes instead of an hour; ``pbar_update_period`` (reference: 1,
+    i.e. one device-to-host read of KL and MNLL per epoch; fast path default 500); ``optimizer_kwargs`` for
+    ``make_optimizer`` (``lambda0`` enters the rate squared -- the defaults give 1e-6)."""
+    import numpy as np
+    from sklearn.model_selection import train_test_split
+    from sklearn.preprocessing import StandardScaler
+    from torch.utils.data import DataLoader, TensorDataset
+    from whvi_amd.layers import WHVILinear
+    from whvi_amd.networks import WHVIRegression
+
+    assert len(y.shape) == 2
+    assert len(X.shape) == 2
+    assert len(X) == len(y)
+    device = torch.device(device)
+    if fast is None:
+        fast = device.type == "cuda"
+    if fast and device.type != "cuda":
+        raise RuntimeError("evaluate_bayesian_regression_dnn(fast=True) needs a GPU device")
+    if pbar_update_period is None:
+        pbar_update_period = 500 if fast else 1
+
+    test_errors, test_mnlls = [], []
+    X = StandardScaler().fit_transform(X)
+    for index in range(n_splits):
+        print(f'Iteration {index + 1}/{n_splits}')
+        X_train, X_test, y_train, y_test = train_test_split(X, y, train_size=0.9, test_size=0.1, random_state=random_state)
+        X_train, y_train = torch.tensor(X_train, device=device), torch.tensor(y_train, device=device)
+        X_test, y_test = torch.tensor(X_test, device=device), torch.tensor(y_test, device=device)
+        if fast:
+            train_loader = DeviceBatches(X_train, y_train, batch_size=batch_size)
+        else:
+            train_loader = DataLoader(TensorDataset(X_train, y_train), batch_size=batch_size)
+
+        model = WHVIRegression([
+            WHVILinear(X_test.size()[1], hidden, lambda_=3.0),
+            nn.ReLU(),
+            WHVILinear(hidden, hidden, lambda_=3.0),
+            nn.ReLU(),
+            WHVILinear(hidden, y_test.size()[1])
+        ], eval_samples=eval_samples)
+        model = model.to(device=device)
+        optimizer, scheduler = make_optimizer(model, capturable=bool(fast), packed=bool(fast), **(optimizer_kwargs or {}))
+
+        iteration_dir = pathlib.Path(checkpoint_dir) / f'iter-{index}'
+        iteration_dir.mkdir(exist_ok=True, parents=True)
+        model.train_model(train_loader, optimizer, scheduler, epochs1=epochs1, epochs2=epochs2,
+                          pbar_update_period=pbar_update_period, checkpoint_dir=iteration_dir, graphed=bool(fast),
+                          sharded=False)
+
+        with torch.no_grad():
+            error, mnll = model.eval_model(X_test, y_test)
+        print(f"Error: {error}, MNLL: {mnll}")
+        test_errors.append(error)
+        test_mnlls.append(mnll)
+
+    return float(np.mean(test_errors)), float(np.std(test_errors)), float(np.mean(test_mnlls)), float(np.std(test_mnlls))

@@ -152,8 +152,9 @@ class GraphedTrainStep:
         philox = [(m, m._rng_state.clone()) for m in net.modules() if torch.is_tensor(getattr(m, "_rng_state", None))]
         if static_eps:
             for module in net.modules():
-                if hasattr(type(module), "inkernel_rng"):
-                    module._eps_static = True                # allocated by the layer's first draw (the warm-up)
+                if hasattr(type(module), "inkernel_rng") and not torch.is_tensor(getattr(module, "_eps_static", None)):
+                    module._eps_static = True                # allocated by the layer's first draw (the warm-up); a buffer
+                                                             # another captured step already reads is kept and shared
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         # A stale autograd graph keeps the parameters' AccumulateGrad nodes alive on the stream that created them; the
@@ -191,7 +192,8 @@ class GraphedTrainStep:
             for module, value in philox:
                 module._rng_state.copy_(value)
         torch.cuda.set_rng_state(saved_rng, dev)
-        self.eps_buffers = [m._eps_static for m in net.modules() if torch.is_tensor(getattr(m, "_eps_static", None))]
+        self._eps_owners = [(m, m._eps_static) for m in net.modules() if torch.is_tensor(getattr(m, "_eps_static", None))]
+        self.eps_buffers = [buf for _, buf in self._eps_owners]
         stale = [w for w in caught if "AccumulateGrad node's stream" in str(w.message)]
         for w in caught:                             # everything else is passed on unchanged
             if w not in stale:
@@ -202,11 +204,16 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         optimizer.zero_grad(set_to_none=True)
         with torch.cuda.graph(self.graph):
-            self.static_loss = net.loss(self.static_x, self.static_y, self.n, ignore_kl=self.ignore_kl)
-            self.static_loss.backward()
+            loss = net.loss(self.static_x, self.static_y, self.n, ignore_kl=self.ignore_kl)
+            loss.backward()
             optimizer.step()
             if scheduler is not None:
                 scheduler.step()
+            # keep the VALUE's static buffer, not the autograd graph recorded during the capture: that graph (and the
+            # gradient accumulators it holds) must not outlive the capture, or a second captured step for the same
+            # network -- another batch shape -- would find it as a stale graph of an earlier pass
+            self.static_loss = loss.detach()
+            del loss
 
     def _eager_step(self):
         self.optimizer.zero_grad(set_to_none=True)
@@ -220,15 +227,16 @@ class GraphedTrainStep:
 
     def release_static_eps(self):
         """Give the layers their generator back (the captured graph keeps reading the static buffers)."""
-        self._eps_owners = [(m, m._eps_static) for m in self.net.modules()
-                            if torch.is_tensor(getattr(m, "_eps_static", None))] or getattr(self, "_eps_owners", [])
-        for module in self.net.modules():
-            if getattr(module, "_eps_static", None) is not None:
+        for module, buf in self._eps_owners:
+            if module._eps_static is buf:
+                module._eps_static = None
+        for module in self.net.modules():                    # containers that were marked but never drew themselves
+            if getattr(module, "_eps_static", None) is True:
                 module._eps_static = None
 
     def restore_static_eps(self):
-        """Undo ``release_static_eps`` (eager steps beside the graph read the same buffers again)."""
-        for module, buf in getattr(self, "_eps_owners", []):
+        """Undo ``release_static_eps`` (eager steps and further captured steps beside this one read the same buffers)."""
+        for module, buf in self._eps_owners:
             module._eps_static = buf
 
     def __call__(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
@@ -237,4 +245,4 @@ class GraphedTrainStep:
         self.static_x.copy_(x)
         self.static_y.copy_(y)
         self.graph.replay()
-        return self.static_loss.detach()
+        return self.static_loss

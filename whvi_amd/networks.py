@@ -145,28 +145,17 @@ class WHVINetwork(nn.Module, WHVI):
                     self.zero_grad(set_to_none=set_to_none)
                     continue
                 if graphed is not None:
-                    # the whole step -- loss, backward, optimizer.step(), scheduler.step() -- as one hipGraph replay;
-                    # captured on the first batch, batches of another shape (a ragged last one) take the eager step
-                    if graphed.get("step") is None:
-                        from whvi_amd.graphs import GraphedTrainStep
-                        kept = getattr(self, "_train_graph", None)       # a later train_model call continues on the same graph
-                        options = graphed.get("options", {})
-                        if (kept is not None and kept.optimizer is optimizer and kept.scheduler is scheduler and kept.n == n
-                                and kept.ignore_kl == bool(ignore_kl) and kept.matches(data_x, data_y)
-                                and bool(options.get("static_eps", False)) == bool(kept.eps_buffers)):
-                            kept.restore_static_eps()
-                            graphed["step"] = kept
-                        else:
-                            graphed["step"] = self._train_graph = GraphedTrainStep(
-                                self, optimizer, data_x, data_y, n, ignore_kl=ignore_kl, scheduler=scheduler, **options)
-                    step = graphed["step"]
-                    if step.matches(data_x, data_y):
+                    # the whole step -- loss, backward, optimizer.step(), scheduler.step() -- as one hipGraph replay, one
+                    # captured step per batch shape (a data set whose size is no multiple of the batch size has two: the
+                    # full batch and the short last one); any further shape takes the eager step
+                    step = self._graphed_step_for(graphed, data_x, data_y, n, optimizer, scheduler, ignore_kl)
+                    if step is not None:
                         hook = graphed.get("before_replay")
                         if hook is not None:
                             hook(step)
                         step(data_x, data_y)
                         continue
-                    # eager step beside a captured one: .grad still names the graph's static buffers -- detach from them
+                    # eager step beside a captured one: .grad still names a graph's static buffers -- detach from them
                     # first, or this backward would accumulate into what the last replay left there
                     self.zero_grad(set_to_none=True)
                 loss = self.loss(data_x, data_y, n=n, ignore_kl=ignore_kl)
@@ -179,6 +168,36 @@ class WHVINetwork(nn.Module, WHVI):
                 torch.save(self.state_dict(), pathlib.Path(checkpoint_dir) / f'epoch-{epoch}.pth')
             if epoch % pbar_update_period == 0:
                 bar.set_description(f'[{label}] KL = {self.current_kl:.2f}, MNLL = {self.current_mnll:.2f}')
+
+    def _graphed_step_for(self, graphed, data_x, data_y, n, optimizer, scheduler, ignore_kl):
+        """The captured step for this batch shape: from this ``train_model`` call, from an earlier one on the same
+        optimizer / schedule / data-set size (``self._train_graphs``: a later call continues on the same graphs), or
+        captured now -- up to ``max_shapes`` of them; ``None`` = take the eager step."""
+        key = (tuple(data_x.shape), tuple(data_y.shape), data_x.dtype, bool(ignore_kl))
+        step = graphed["steps"].get(key)
+        if step is not None:
+            return step
+        from whvi_amd.graphs import GraphedTrainStep
+        options = graphed["options"]
+        kept = getattr(self, "_train_graphs", None)
+        if kept is None or kept["optimizer"] is not optimizer or kept["scheduler"] is not scheduler or kept["n"] != n \
+                or kept["static_eps"] != bool(options.get("static_eps", False)):
+            kept = self._train_graphs = {"optimizer": optimizer, "scheduler": scheduler, "n": n, "steps": {},
+                                         "static_eps": bool(options.get("static_eps", False))}
+        step = kept["steps"].get(key)
+        if step is not None:
+            step.restore_static_eps()
+        elif sum(1 for k in kept["steps"] if k[3] == key[3]) < graphed["max_shapes"]:
+            for other in kept["steps"].values():
+                other.restore_static_eps()                   # a new capture shares the static eps buffers of the others
+            step = kept["steps"][key] = GraphedTrainStep(self, optimizer, data_x, data_y, n, ignore_kl=ignore_kl,
+                                                         scheduler=scheduler, **options)
+        else:
+            return None
+        graphed["steps"][key] = step
+        if graphed.get("first") is None:
+            graphed["first"] = step
+        return step
 
     @staticmethod
     def _is_rank_zero():
@@ -198,7 +217,9 @@ class WHVINetwork(nn.Module, WHVI):
         ``make_optimizer(net, capturable=True[, packed=True])``.  ``packed=True`` additionally insists that the stacked
         layers use the packed parameter layout (it has to be chosen BEFORE the optimizer is created: the optimizer holds
         the parameter tensors).  ``graph_options``: keyword arguments for ``GraphedTrainStep`` (``static_eps``, ``warmup``)
-        plus an optional ``before_replay(step)`` callable run ahead of every replay.
+        plus an optional ``before_replay(step)`` callable run ahead of every replay and ``max_shapes`` (default 2): how
+        many batch shapes get a captured step of their own -- the full batch and a short last one; further shapes take the
+        eager step.  Returns the captured step of the first batch shape (``None`` when not graphed).
 
         ``sharded`` (not in the reference, which is single-process): ``None`` = automatically when a ``torch.distributed``
         process group is initialised, ``True`` / ``False`` to force.  The ``train_samples`` Monte-Carlo samples of every
@@ -219,7 +240,8 @@ class WHVINetwork(nn.Module, WHVI):
         state = None
         if graphed:
             options = dict(graph_options or {})
-            state = {"step": None, "before_replay": options.pop("before_replay", None), "options": options}
+            state = {"steps": {}, "first": None, "before_replay": options.pop("before_replay", None),
+                     "max_shapes": int(options.pop("max_shapes", 2)), "options": options}
         self.train()
         self.likelihood.requires_grad = False
         self._epochs(data_loader, optimizer, scheduler, epochs1, 'Fixed LH', ignore_kl, pbar_update_period,
@@ -227,17 +249,18 @@ class WHVINetwork(nn.Module, WHVI):
         self.likelihood.requires_grad = True
         self._epochs(data_loader, optimizer, scheduler, epochs2, 'Optimized LH', ignore_kl, pbar_update_period,
                      checkpoint_dir=checkpoint_dir, graphed=state, sharded=sharded)
-        if state is not None and state["step"] is not None:
-            state["step"].release_static_eps()
+        if state is not None:
+            for step in state["steps"].values():
+                step.release_static_eps()
         self.eval()
-        return state["step"] if state is not None else None
+        return state["first"] if state is not None else None
 
     def eval_model(self, X_test, y_test, loss) -> Tuple[float, float]:
         """(test error, test MNLL) with ``eval_samples`` draws (src/networks.py:101-115)."""
         self.eval()
         y_pred = self(X_test)
         test_mnll = self.likelihood.mnll_batch_estimate(y_test, y_pred, n=y_test.size(0))
-        return float(loss(y_pred, y_test)), float(test_mnll)
+        return float(loss(y_pred, y_test).detach()), float(test_mnll.detach())
 
 
 def _rmse_of_mean(y_pred, y_true):
