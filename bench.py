@@ -594,6 +594,20 @@ def _extra_config4_train(device):
     return out
 
 
+def _extra_evaluation_harness(device):
+    """The reference's UCI regression protocol (``evaluate_bayesian_regression_dnn``, src/evaluation.py:30-108) on a synthetic
+    data set of the yacht data's shape: optimisation steps per second of the reference's flow (DataLoader, host schedule,
+    eager steps) and of the fast path (packed, device-resident Adam + schedule, one hipGraph replay per step).  A child
+    process (tools/evaluation_harness_rate.py) with its exit code in the line."""
+    import subprocess
+    child = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "evaluation_harness_rate.py")],
+                           capture_output=True, text=True, timeout=600)
+    line = [ln for ln in child.stdout.splitlines() if ln.startswith("{")]
+    out = json.loads(line[-1]) if line else {"error": child.stderr.strip().splitlines()[-3:]}
+    out["child_exit_code"] = child.returncode
+    return out
+
+
 def extras(device):
     """Secondary measurements (inputs resident, HIP-event timed).  Every section is independent: a failure is
     recorded under its own key and never costs the other numbers or the headline line."""
@@ -606,7 +620,8 @@ def extras(device):
                     ("wbar_bwd", _extra_wbar_bwd),
                     ("whvilinear_512_fwd_kl_32mc_b4096", _extra_layer),
                     ("whviregression_3_1024_1024_1_mc16", _extra_network), ("toy_regression", _extra_toy),
-                    ("config4_train_step", _extra_config4_train)):
+                    ("config4_train_step", _extra_config4_train),
+                    ("uci_protocol_yacht_shape", _extra_evaluation_harness)):
         try:
             out[key] = fn(device)
         except Exception as err:

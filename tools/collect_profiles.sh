@@ -58,6 +58,8 @@ else
   python3 tools/probe_fused_inst.py batch-major,sample-major > "$out/fused_instantiations_hip_events.log" 2>&1
   python3 tools/probe_wbar_mean.py > "$out/wbar_mean_one_vs_two_launches.log" 2>&1
   python3 tools/config4_train_step.py 2> /dev/null | tail -1 > "$out/config4_train_step_recipe.json"
+  python3 tools/evaluation_harness_rate.py 2> /dev/null | tail -1 > "$out/uci_protocol_yacht_shape.json"
+  python3 tools/probe_wbar_fwd_stream.py > "$out/wbar_fwd_stream_hip_events.log" 2>&1
   python3 bench.py > "$out/bench_N1.json" 2> "$raw/bench_N1.err"
 fi
 ls -la "$out"
