@@ -281,6 +281,15 @@ int whvi_gauss_mnll_bwd_f32(void *grad_yhat, void *grad_sigma, const void *grad_
                             const void *y, const void *y_hat, const void *sigma, const int64_t *size,
                             const int64_t *yhat_stride, const int64_t *y_stride, float scale, void *stream);
 
+/* Learning-rate schedule of the reference's experiments on the device (src/evaluation.py:25-26: LambdaLR with
+ * lambda t: lambda0 * (1 + gamma * t) ** (-p); src/networks.py:80-81 steps it after every batch):
+ *     if (advance) *t += 1;   *lr = (float)(base_lr * (lambda0 * pow(1 + gamma * *t, -p)))
+ * t: DEVICE double (the step counter), lr: DEVICE float (the rate a capturable Adam reads).  One single-thread launch,
+ * capture-safe; float64 arithmetic like LambdaLR's Python floats, one rounding to float32.  With several parameter
+ * groups call it once per group, advance = 1 on the first only. */
+int whvi_decay_lr_step(void *t, void *lr, double base_lr, double lambda0, double gamma, double p, int advance,
+                       void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -123,6 +123,9 @@ def test_argument_checks_of_the_training_step_entry_points():
     assert L.whvi_gauss_mnll_bwd_f32(None, None, p16, p16, p16, p16, p16, i64x3(1, 1, 1), i64x3(1, 1, 1), i64x3(1, 1, 0),
                                      1.0, None) == -1
     assert L.whvi_gauss_mnll_blocks(1) == 1 and L.whvi_gauss_mnll_blocks(10 ** 9) == 2048
+    assert L.whvi_decay_lr_step(None, p16, 1.0, 1.0, 1.0, 1.0, 1, None) == -1 and "null" in _hip.last_error()
+    assert L.whvi_decay_lr_step(p16 + 4, p16, 1.0, 1.0, 1.0, 1.0, 1, None) == -3
+    assert L.whvi_decay_lr_step(p16, p16 + 2, 1.0, 1.0, 1.0, 1.0, 1, None) == -3
 
 
 def test_last_kernel_before_any_launch():

@@ -310,6 +310,48 @@ def test_device_resident_schedule_is_the_reference_schedule():
 
 
 @pytest.mark.gpu
+def test_one_launch_schedule_is_the_reference_schedule_gpu(hip_lib):
+    """``DeviceDecayLR`` (what ``make_optimizer(capturable=True)`` returns: ``whvi_decay_lr_step``, one single-thread launch
+    per step) against the reference's host-side ``LambdaLR`` (src/evaluation.py:25-26) over 3 000 steps and against the
+    recorded rates: float32 resolution, the step counter exact, two parameter groups advance together, state round trip,
+    and the generic ``DeviceLambdaLR`` (tensor ops) agrees with it."""
+    from whvi_amd.evaluation import DeviceDecayLR, DeviceLambdaLR, make_optimizer
+    g = _npz("train_golden.npz")
+    for run, lam0 in (("default", 0.001), ("fast", 0.05)):
+        net = nn.Linear(2, 2).to("cuda")
+        opt, sched = make_optimizer(net, lambda0=lam0, capturable=True)
+        assert isinstance(sched, DeviceDecayLR) and opt.defaults.get("fused") is True
+        want = g[f"{run}/lr"]
+        for i in range(len(want)):
+            assert abs(sched.get_last_lr()[0] - want[i]) <= 2e-7 * want[i], (run, i)
+            sched.step()
+        assert float(sched.t) == len(want)
+    a, b = nn.Linear(2, 2).to("cuda"), nn.Linear(3, 3).to("cuda")
+    opt = torch.optim.Adam([{"params": a.parameters(), "lr": 0.01}, {"params": b.parameters(), "lr": 0.002}], capturable=True)
+    sched = DeviceDecayLR(opt, 0.001, 0.0005, 0.3)
+    twin = torch.optim.Adam([{"params": a.parameters(), "lr": 0.01}, {"params": b.parameters(), "lr": 0.002}], capturable=True)
+    generic = DeviceLambdaLR(twin, lambda t: 0.001 * torch.pow(1.0 + 0.0005 * t, -0.3))
+    host_opt = torch.optim.Adam([{"params": nn.Linear(2, 2).parameters(), "lr": 0.01},
+                                 {"params": nn.Linear(3, 3).parameters(), "lr": 0.002}])
+    host = torch.optim.lr_scheduler.LambdaLR(host_opt, lambda t: 0.001 * ((1 + 0.0005 * t) ** (-0.3)))
+    for i in range(3000):
+        if i % 250 == 0 or i < 8:
+            for got, other, ref in zip(sched.get_last_lr(), generic.get_last_lr(), host.get_last_lr()):
+                assert abs(got - ref) <= 1.2e-7 * ref and abs(other - ref) <= 1.2e-7 * ref, (i, got, other, ref)
+        sched.step()
+        generic.step()
+        host_opt.step()
+        host.step()
+    assert float(sched.t) == 3000.0
+    state = sched.state_dict()
+    sched.load_state_dict({"t": 7.0, "base_lrs": state["base_lrs"]})
+    assert abs(sched.get_last_lr()[1] - 0.002 * 0.001 * (1 + 0.0005 * 7) ** -0.3) <= 1.2e-7 * 2e-6
+    from whvi_amd import _hip
+    with pytest.raises(RuntimeError):
+        _hip.decay_lr_step(torch.zeros((), device="cuda"), torch.zeros((), device="cuda"), 1.0, 1.0, 1.0, 1.0)   # t not float64
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("packed", [False, True])
 @pytest.mark.parametrize("run", ["default", "fast"])
 def test_train_trajectory_graphed_vs_reference_gpu(run, packed, tmp_path, hip_lib):

@@ -75,6 +75,8 @@ def _declare_f3(lib):
     lib.whvi_gauss_mnll_blocks.argtypes = [i64]
     lib.whvi_gauss_mnll_f32.restype = ctypes.c_int
     lib.whvi_gauss_mnll_f32.argtypes = [vp, vp, vp, vp, p64, p64, p64, ctypes.c_float, vp]
+    lib.whvi_decay_lr_step.restype = ctypes.c_int
+    lib.whvi_decay_lr_step.argtypes = [vp, vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int32, vp]
     lib.whvi_gauss_mnll_bwd_f32.restype = ctypes.c_int
     lib.whvi_gauss_mnll_bwd_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, p64, p64, p64, ctypes.c_float, vp]
     for sfx in ("f32", "f64"):
@@ -462,6 +464,19 @@ def gauss_mnll(y: torch.Tensor, y_hat: torch.Tensor, sigma: torch.Tensor, scale:
                                    float(scale), _stream(y_hat))
     _check(rc, "whvi_gauss_mnll")
     return part
+
+
+def decay_lr_step(t: torch.Tensor, lr: torch.Tensor, base_lr: float, lambda0: float, gamma: float, p: float,
+                  advance: bool = True) -> None:
+    """whvi_decay_lr_step: ``t`` (0-d float64) += 1 when ``advance``; ``lr`` (0-d float32) <- base_lr * lambda0 *
+    (1 + gamma t)^-p.  One single-thread launch on the current stream (capture-safe)."""
+    if t.dtype != torch.float64 or lr.dtype != torch.float32 or t.numel() != 1 or lr.numel() != 1 or t.device != lr.device \
+            or t.device.type != "cuda":
+        raise RuntimeError("decay_lr_step: t must be a float64 and lr a float32 device scalar on the same GPU")
+    with _OnDevice(t.device):
+        rc = lib().whvi_decay_lr_step(t.data_ptr(), lr.data_ptr(), float(base_lr), float(lambda0), float(gamma), float(p),
+                                      1 if advance else 0, _stream(t))
+    _check(rc, "whvi_decay_lr_step")
 
 
 def gauss_mnll_bwd(grad_out, part, y, y_hat, sigma, scale: float):

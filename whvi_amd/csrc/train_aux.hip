@@ -286,3 +286,32 @@ int whvi_gauss_mnll_bwd_f32(void *grad_yhat, void *grad_sigma, const void *grad_
                        scale);
     return after_launch("gauss_mnll_bwd");
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Learning-rate schedule of the reference's experiments, on the device (src/evaluation.py:25-26: LambdaLR with
+// lambda t: lambda0 * (1 + gamma t)^-p, stepped after EVERY batch, src/networks.py:80-81).  One thread: advance the step
+// counter and write the rate Adam reads from device memory -- one graph node instead of the seven tiny float64 torch ops
+// the same update takes as tensor arithmetic.  float64 like Python's arithmetic in LambdaLR, one rounding to the float32 rate.
+namespace whvi {
+__global__ void decay_lr_kernel(double *t, float *lr, double base_lr, double lambda0, double gamma, double p, int advance)
+{
+    double step = *t;
+    if (advance) {
+        step += 1.0;
+        *t = step;
+    }
+    *lr = (float)(base_lr * (lambda0 * pow(1.0 + gamma * step, -p)));
+}
+}  // namespace whvi
+
+extern "C" __attribute__((visibility("default")))
+int whvi_decay_lr_step(void *t, void *lr, double base_lr, double lambda0, double gamma, double p, int advance, void *stream)
+{
+    g_err[0] = 0;
+    if (!t || !lr) return fail(WHVI_ERR_ARG, "whvi_decay_lr_step: null pointer%s", "");
+    if ((uintptr_t)t & 7) return fail(WHVI_ERR_ALIGN, "whvi_decay_lr_step: %s pointer is not 8-byte aligned", "t");
+    if ((uintptr_t)lr & 3) return fail(WHVI_ERR_ALIGN, "whvi_decay_lr_step: %s pointer is not 4-byte aligned", "lr");
+    hipLaunchKernelGGL(decay_lr_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (double *)t, (float *)lr, base_lr, lambda0,
+                       gamma, p, advance);
+    return after_launch("decay_lr_step");
+}

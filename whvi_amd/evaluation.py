@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 import torch.optim as optim
 
-__all__ = ["make_optimizer", "DeviceLambdaLR", "DeviceBatches", "evaluate_bayesian_regression_dnn"]
+__all__ = ["make_optimizer", "DeviceLambdaLR", "DeviceDecayLR", "DeviceBatches", "evaluate_bayesian_regression_dnn"]
 
 
 class DeviceLambdaLR:
@@ -65,7 +65,29 @@ class DeviceLambdaLR:
         self._apply()
 
 
-def make_optimizer(net, gamma=0.0005, p=0.3, lambda0=0.001, capturable=False, packed=False):
+class DeviceDecayLR(DeviceLambdaLR):
+    """``DeviceLambdaLR`` for the one schedule the reference's experiments use -- ``lambda t: lambda0 * (1 + gamma t)^-p``
+    (src/evaluation.py:25-26) -- with ``step()`` as ONE single-thread launch per parameter group
+    (``whvi_decay_lr_step``) instead of seven tiny float64 tensor ops: in a captured training step of ~60 launches every
+    graph node is 2 us."""
+
+    def __init__(self, optimizer, lambda0, gamma, p, base_lrs=None):
+        self.lambda0, self.gamma, self.p = float(lambda0), float(gamma), float(p)
+        super().__init__(optimizer, lambda t: self.lambda0 * torch.pow(1.0 + self.gamma * t, -self.p), base_lrs=base_lrs)
+
+    def _launch(self, advance):
+        from whvi_amd import _hip
+        for i, (group, base) in enumerate(zip(self.optimizer.param_groups, self.base_lrs)):
+            _hip.decay_lr_step(self.t, group["lr"], base, self.lambda0, self.gamma, self.p, advance=advance and i == 0)
+
+    def _apply(self):
+        self._launch(False)
+
+    def step(self):
+        self._launch(True)
+
+
+def make_optimizer(net, gamma=0.0005, p=0.3, lambda0=0.001, capturable=False, packed=False, fused=None):
     """Adam plus the decaying schedule of the reference's experiments; returns ``(optimizer, scheduler)``.
 
     Kept exactly as the reference behaves, including its quirk: ``LambdaLR`` MULTIPLIES the optimizer's base
@@ -77,8 +99,9 @@ def make_optimizer(net, gamma=0.0005, p=0.3, lambda0=0.001, capturable=False, pa
     Training trajectories recorded from the reference (tests/golden/train_golden.npz) are replayed against this.
 
     ``capturable=True`` (not in the reference) builds the SAME recipe for ``WHVINetwork.train_model(..., graphed=True)``:
-    Adam keeps its state and its learning rate on the device and the schedule is a ``DeviceLambdaLR``, so one captured
-    hipGraph holds loss, backward, ``optimizer.step()`` and ``scheduler.step()``.  ``packed=True`` first switches every
+    Adam (torch's fused multi-tensor kernel unless ``fused=False``) keeps its state and its learning rate on the device and
+    the schedule is a ``DeviceDecayLR`` (one launch per step), so one captured hipGraph holds loss, backward,
+    ``optimizer.step()`` and ``scheduler.step()``.  ``packed=True`` first switches every
     stacked layer to the packed parameter layout (``WHVINetwork.pack_parameters``: checkpoints keep the reference's keys).
 
     :param net: target model.
@@ -95,8 +118,14 @@ def make_optimizer(net, gamma=0.0005, p=0.3, lambda0=0.001, capturable=False, pa
     device = next(net.parameters()).device
     if device.type != "cuda":
         raise RuntimeError("make_optimizer(capturable=True) needs the network on a GPU")
-    optimizer = optim.Adam(net.parameters(), lr=torch.tensor(lambda0, dtype=torch.float32, device=device), capturable=True)
-    scheduler = DeviceLambdaLR(optimizer, lambda t: lambda0 * torch.pow(1.0 + gamma * t, -p), base_lrs=[lambda0])
+    # fused=True: torch's one-launch multi-tensor Adam.  The default (foreach) implementation with capturable=True spends
+    # ~42 launches per step on this network -- among them one broadcast division PER PARAMETER TENSOR for each of the two
+    # bias corrections, whose 0-d step tensors take _foreach_div_ off its fast path -- i.e. 40 % of a captured step
+    # (profiles/r03/train_graph_kernels.log).  Same update formula; float32 rounding of intermediate terms may differ.
+    fused = True if fused is None else bool(fused)
+    optimizer = optim.Adam(net.parameters(), lr=torch.tensor(lambda0, dtype=torch.float32, device=device), capturable=True,
+                           fused=fused)
+    scheduler = DeviceDecayLR(optimizer, lambda0, gamma, p, base_lrs=[lambda0])
     return optimizer, scheduler
 
 
