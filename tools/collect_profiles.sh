@@ -48,10 +48,13 @@ else
   trace config4 "$root/tools/profile_config4.py"
   trace wbar_bwd "$root/tools/profile_wbar_bwd.py" 10
   trace wbar_fwd "$root/tools/profile_wbar_fwd.py"
+  trace train_graph "$root/tools/profile_train_graph.py" 300
   cd "$root"
   python3 tools/summarize_profile.py "$out/fused_instantiations_rocprof_summary.csv" 8589934592 "$raw/fused_inst_trace" "$raw/fused_inst_FETCH_SIZE" "$raw/fused_inst_WRITE_SIZE" "$raw/fused_inst_SQ_WAVES"
   python3 tools/filter_stats.py "$(find $raw/config2_trace -name "*kernel_stats.csv" | head -1)" "$out/config2_kernel_time_shares.csv"
   python3 tools/filter_stats.py "$(find $raw/config4_trace -name "*kernel_stats.csv" | head -1)" "$out/config4_train_step_kernel_shares.csv"
+  python3 tools/filter_stats.py "$(find $raw/train_graph_trace -name "*kernel_stats.csv" | head -1)" "$out/train_graph_kernel_shares.csv"
+  find "$raw/train_graph_trace" -name "*kernel_trace.csv" -delete     # 20 k rows: only the per-kernel statistics are kept
   python3 tools/summarize_profile.py "$out/wbar_bwd_kernel_trace_summary.csv" 0 "$raw/wbar_bwd_trace"
   python3 tools/summarize_profile.py "$out/wbar_fwd_kernel_trace_summary.csv" 0 "$raw/wbar_fwd_trace"
   cp "$raw/wbar_bwd_trace.log" "$out/wbar_bwd_shapes.log"; cp "$raw/wbar_fwd_trace.log" "$out/wbar_fwd_shapes.log"; cp "$raw/fused_inst_trace.log" "$out/fused_instantiations_symbols.log"

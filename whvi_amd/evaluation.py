@@ -121,7 +121,7 @@ def make_optimizer(net, gamma=0.0005, p=0.3, lambda0=0.001, capturable=False, pa
     # fused=True: torch's one-launch multi-tensor Adam.  The default (foreach) implementation with capturable=True spends
     # ~42 launches per step on this network -- among them one broadcast division PER PARAMETER TENSOR for each of the two
     # bias corrections, whose 0-d step tensors take _foreach_div_ off its fast path -- i.e. 40 % of a captured step
-    # (profiles/r03/train_graph_kernels.log).  Same update formula; float32 rounding of intermediate terms may differ.
+    # (profiles/r03/train_graph_before_after.log).  Same update formula; float32 rounding of intermediate terms may differ.
     fused = True if fused is None else bool(fused)
     optimizer = optim.Adam(net.parameters(), lr=torch.tensor(lambda0, dtype=torch.float32, device=device), capturable=True,
                            fused=fused)
