@@ -18,7 +18,7 @@ net = WHVIRegression([WHVILinear(1, 128), nn.ReLU(), WHVILinear(128, 128), nn.Re
                      train_samples=1).to(dev).train()
 x = torch.linspace(-2, 2, 100, device=dev).unsqueeze(1)
 y = torch.sin(3 * x)
-opt = torch.optim.Adam(net.parameters(), lr=1e-3, capturable=True)
+opt = torch.optim.Adam(net.parameters(), lr=1e-3, capturable=True, fused=True)     # one launch (the foreach form: 42)
 step = GraphedTrainStep(net, opt, x, y, n=100)
 first = float(step(x, y))
 for _ in range(50):
