@@ -95,7 +95,7 @@ class WHVINetwork(nn.Module, WHVI):
         axis ``(S, batch, features)`` from the first WHVI layer on; deterministic modules broadcast
         over it.  Same output layout as the loop: ``(batch, out_dim, n_samples)``."""
         h = x
-        fused_kl, complete = 0.0, True
+        fused_kl, complete = None, True
         for module in self.sequential:
             if hasattr(module, "forward_mc"):
                 h = module.forward_mc(h, n_samples)
@@ -104,7 +104,7 @@ class WHVINetwork(nn.Module, WHVI):
                 if kl is None:
                     complete = False
                 else:
-                    fused_kl = fused_kl + kl
+                    fused_kl = kl if fused_kl is None else fused_kl + kl
             else:
                 h = module(h)
                 complete = complete and 'kl' not in dir(module)
