@@ -92,24 +92,29 @@ def test_fused_streaming_instantiation_vs_oracle(dtype, log2d, per_sample, layou
         assert np.array_equal(x[tidx].cpu().numpy(), src_rows), "out-of-place must leave the source untouched"
 
 
-@pytest.mark.parametrize("D,S", [(2048, 12), (512, 170), (4096, 3)])
-def test_weight_construction_f64_at_streaming_size(D, S, hip_lib):
-    """whvi_wbar_fwd_f64 with the mean matrix added, > 256 MiB of matrices (non-temporal stores, XCD-sliced order):
-    sampled rows bit for bit against ``oracle.pipeline`` on one-hot rows (row i of diag(s2): the dataflow of
-    src/weights.py:73) plus ONE f64 add of the mean row (src/weights.py:93); off-diagonals exactly zero."""
+@pytest.mark.parametrize("dtype,D,S", [(torch.float64, 2048, 12), (torch.float64, 512, 170), (torch.float64, 4096, 3),
+                                       (torch.float32, 2048, 20), (torch.float32, 512, 340), (torch.float32, 4096, 5)])
+def test_weight_construction_at_streaming_size(dtype, D, S, hip_lib):
+    """whvi_wbar_fwd_f32 / _f64 with the mean matrix added, > 256 MiB of matrices (the write-only streaming launch:
+    non-temporal global stores, XCD-sliced order -- the instantiations ``extras.wbar_fwd`` times): sampled rows bit for bit
+    against ``oracle.pipeline`` on one-hot rows (row i of diag(s2): the dataflow of src/weights.py:73) plus ONE add of the
+    mean row (src/weights.py:93); off-diagonals exactly zero; every row of every matrix written."""
     g = torch.Generator(device=DEV).manual_seed(D + S)
-    s1, s2 = (torch.randn(1, D, device=DEV, dtype=torch.float64, generator=g) for _ in range(2))
-    u = torch.randn(1, 1 + S, D, device=DEV, dtype=torch.float64, generator=g)
+    s1, s2 = (torch.randn(1, D, device=DEV, dtype=dtype, generator=g) for _ in range(2))
+    u = torch.randn(1, 1 + S, D, device=DEV, dtype=dtype, generator=g)
     mean = _hip.wbar_fwd(s1, u, s2, D, first=0, count=1).view(1, D, D)
     full = _hip.wbar_fwd(s1, u, s2, D, base=mean, first=1)                                   # (1, S, D, D)
     log2d = D.bit_length() - 1
-    assert full.numel() * 8 > 256 * MIB
-    assert _hip.last_kernel() == f"whvi::wbar_fwd_kernel<double, {log2d}, {32 if D == 4096 else 16}, true>", _hip.last_kernel()
+    assert full.numel() * full.element_size() > 256 * MIB
+    name = "double" if dtype == torch.float64 else "float"
+    assert _hip.last_kernel() == f"whvi::wbar_fwd_kernel<{name}, {log2d}, {32 if (D == 4096 and dtype == torch.float64) else 16}, true>", \
+        _hip.last_kernel()
+    assert bool((full[0].diagonal(dim1=1, dim2=2) != 0).all())                               # every row of every matrix
     rng = np.random.default_rng(D)
     ks = np.unique(np.concatenate([[0, S - 1], rng.integers(0, S, 6)]))
     iis = np.unique(np.concatenate([[0, 1, 63, 64, D - 1], rng.integers(0, D, 11)]))
     s1n, s2n, un = s1[0].cpu().numpy(), s2[0].cpu().numpy(), u[0].cpu().numpy()
-    onehot = np.eye(D, dtype=np.float64)[iis]
+    onehot = np.eye(D, dtype=np.float64 if dtype == torch.float64 else np.float32)[iis]
     n = len(iis)
     kw = dict(n_samples=1, sample_stride=n, group_rows=n, axis="row")
     want_mean = oracle.pipeline(onehot, s1n[iis], un[0][iis], s2n[iis], **kw)
