@@ -201,7 +201,7 @@ inline void launch_rows(void *dst, const void *src, int64_t n_chunks, int varian
             // tiles of more than 64 data VGPRs (one row per wave: f32 D = 8192, f64 D = 4096): 256-thread blocks
             // either way; streams get the non-temporal accesses and the store barrier as well
             if (big && nt) {
-                constexpr bool SG = sizeof(T) == 8 && WHVI_F64_STREAM_FORM == 3;   // tuning: the signed network here loses (6.23 vs 6.31)
+                constexpr bool SG = (sizeof(T) == 8 || std::is_same<T, float>::value) && WHVI_F64_STREAM_FORM == 3;   // tuning: the signed network here loses (6.23 vs 6.31)
                 note_launch<T>("fwht_rows_kernel", LOG2D, K, POLICY_DPP, false, true, 256, 1, SG);
                 hipLaunchKernelGGL((fwht_rows_kernel<T, LOG2D, K, POLICY_DPP, false, true, 256, 1, SG>),
                                    dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, st, d, s, n_chunks, n_tiles);

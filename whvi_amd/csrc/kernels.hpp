@@ -242,12 +242,24 @@ __device__ __forceinline__ void uniform_st16(void *base, uint32_t bytes, int lan
     __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, lane * 16, byte_offset, NT ? ((WRITE_THROUGH ? (1 << 4) : 0) | (1 << 1)) : 0);
 }
 
+// Occupancy target of fwht_rows_kernel.  One-row tiles of 128 data registers (f32 / i32 D = 8192, f64 D = 4096) are
+// compiled to 241 VGPRs = two waves per SIMD when left alone.  Round 3 measured the f32 one at THREE (168 VGPRs, measurement
+// builds -DWHVI_WIDE_TILE_WAVES=3): 5.50 -> 6.09 TB/s -- with 120 B / lane of scratch.  No spill-free form kept the gain
+// (partial tiles through buffer accesses, chunk offsets as scalar offsets, no SLP pairs, the tile loop run once: 0-28 B of
+// scratch, 5.4-5.6 TB/s), so under the no-scratch rule (tools/check_spills.py) the shipped kernel stays at two waves.
+template <typename T, int K, int ALIGN> constexpr int rows_waves_per_eu()
+{
+    // (f32 only: f64 gains nothing from the third wave, 5.88 vs 5.91 TB/s)
+    constexpr bool wide = K * Elem<T>::VEC * (int)sizeof(typename Elem<T>::acc) / 4 > 64 && std::is_same<T, float>::value;
+    return (wide && ALIGN >= 1 && WHVI_WIDE_TILE_WAVES > 0) ? WHVI_WIDE_TILE_WAVES : WHVI_ROWS_WAVES_PER_EU;
+}
+
 // ---- batched row FWHT ------------------------------------------------------------------------
 // dst/src: n_chunks 16-byte chunks; tile t = chunks [t*64*K, (t+1)*64*K).  Only the last tile
 // can be partial; its missing chunks belong to rows that do not exist (rows never straddle
 // tiles), so they are read as zero and never stored.
 template <typename T, int LOG2D, int K, int POLICY, bool PREFETCH, bool NT, int BLOCK = 256, int ALIGN = 0, bool SIGNED = false>
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WHVI_ROWS_WAVES_PER_EU)))
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(rows_waves_per_eu<T, K, ALIGN>())))
 fwht_rows_kernel(u32x4 *dst, const u32x4 *src, int64_t n_chunks, int64_t n_tiles)
 {
     using E = Elem<T>;
@@ -314,12 +326,25 @@ fwht_rows_kernel(u32x4 *dst, const u32x4 *src, int64_t n_chunks, int64_t n_tiles
         for (int k = 0; k < K; ++k) uniform_st16<NT>(dst + tile * TILE, bytes, lane, k * 1024, E::pack(r[k]));
     };
 #else
+    // One-row tiles of 128 data registers: the partial last tile goes through bounds-checked buffer accesses from the
+    // tile's wave-uniform base (reads beyond the buffer return zeros, writes are dropped) instead of 32 guarded accesses
+    // with a 64-bit compare and an address pair each -- registers the 168-VGPR budget of three waves per SIMD does not have.
+    constexpr bool WIDE = K * VEC * (int)sizeof(A) / 4 > 64 && WHVI_WIDE_TILE_WAVES > 0;      // measurement builds only, see rows_waves_per_eu
     auto load_tile = [&](int64_t tile, u32x4 (&raw)[K]) {
         const int64_t base = tile * TILE;
         const u32x4 *p = src + base + lane;
-        if (base + TILE <= n_chunks) {
+        if constexpr (WIDE && NT && WHVI_WIDE_TILE_LOADS == 1) {
+            const int64_t left = n_chunks - base;
+            const uint32_t bytes = (uint32_t)((left < TILE ? left : (int64_t)TILE) * 16);
+#pragma unroll
+            for (int k = 0; k < K; ++k) raw[k] = uniform_ld16<NT>(src + base, bytes, lane, k * 1024);
+        } else if (base + TILE <= n_chunks) {
 #pragma unroll
             for (int k = 0; k < K; ++k) raw[k] = ld16<NT>(p + k * 64);
+        } else if constexpr (WIDE) {
+            const uint32_t bytes = (uint32_t)((n_chunks - base) * 16);
+#pragma unroll
+            for (int k = 0; k < K; ++k) raw[k] = uniform_ld16<NT>(src + base, bytes, lane, k * 1024);
         } else {
 #pragma unroll
             for (int k = 0; k < K; ++k) {
@@ -331,7 +356,15 @@ fwht_rows_kernel(u32x4 *dst, const u32x4 *src, int64_t n_chunks, int64_t n_tiles
     auto store_tile = [&](int64_t tile, A (&r)[K][VEC]) {
         const int64_t base = tile * TILE;
         u32x4 *q = dst + base + lane;
-        if (base + TILE <= n_chunks) {
+        if constexpr (WIDE && NT) {
+            // full or partial alike: the chunk offset rides in the instruction's scalar offset, so the 32 stores need one
+            // VGPR (lane * 16) between them -- as vector offsets (tile_store_stream) they are 31 loop-invariant registers
+            // that the compiler hoists out of the tile loop and then spills
+            const int64_t left = n_chunks - base;
+            const uint32_t bytes = (uint32_t)((left < TILE ? left : (int64_t)TILE) * 16);
+#pragma unroll
+            for (int k = 0; k < K; ++k) uniform_st16<true>(dst + base, bytes, lane, k * 1024, E::pack(r[k]));
+        } else if (base + TILE <= n_chunks) {
             if constexpr (NT) {
 #pragma unroll
                 for (int k = 0; k < K; ++k) tile_store_stream(dst + base, lane, k, E::pack(r[k]), TILE * 16);
@@ -339,6 +372,10 @@ fwht_rows_kernel(u32x4 *dst, const u32x4 *src, int64_t n_chunks, int64_t n_tiles
 #pragma unroll
                 for (int k = 0; k < K; ++k) st16<NT>(q + k * 64, E::pack(r[k]));
             }
+        } else if constexpr (WIDE) {
+            const uint32_t bytes = (uint32_t)((n_chunks - base) * 16);
+#pragma unroll
+            for (int k = 0; k < K; ++k) uniform_st16<NT>(dst + base, bytes, lane, k * 1024, E::pack(r[k]));
         } else {
 #pragma unroll
             for (int k = 0; k < K; ++k)
@@ -347,10 +384,16 @@ fwht_rows_kernel(u32x4 *dst, const u32x4 *src, int64_t n_chunks, int64_t n_tiles
     };
 
 #endif
+    // Store-barrier launches are one tile per wave by construction (their block barriers would not survive a loop whose trip
+    // count differs between the waves of a block).  Whether the CODE still contains the grid-stride loop decides nothing
+    // functionally and a lot in time -- measured, not explained (tools/probe_rows_forms.py, profiles/r03/rows_loop_form_ab.log):
+    // without it f32 / i32 / f64 LOSE 8-9 % (6.41 -> 5.90 TB/s at D = 512 .. 4096: same occupancy, same instruction mix, a
+    // different schedule), 16-bit storage GAINS: fp16 / bf16 D = 8192 5.5 / 5.3 -> 6.1-6.2 / 6.24, D <= 4096 +0.5 %.
+    constexpr bool SINGLE_PASS = ALIGN >= 1 && (WHVI_ALIGN_SINGLE_PASS == 1 || (WHVI_ALIGN_SINGLE_PASS < 0 && sizeof(T) == 2));
     if constexpr (!PREFETCH) {
         // plain grid-stride form: with grid == tiles/waves this is one tile per wave and out; only
         // one tile's worth of registers is ever live (fits a 1024-thread block at 128 VGPRs)
-        for (; t < n_tiles; t += stride) {
+        for (; t < n_tiles; t += SINGLE_PASS ? n_tiles : stride) {
             A r[K][VEC];
             {
                 u32x4 raw[K];

@@ -14,7 +14,7 @@
 #define WHVI_TUNE_ENV(name) ((const char *)nullptr)
 #if defined(WHVI_F16_UNPACK) || defined(WHVI_F16_PACK_EXP) || defined(WHVI_BF16_PACK) || defined(WHVI_ROWS_WAVES_PER_EU) || \
     defined(WHVI_ROWS_PKMASK) || defined(WHVI_FUSED_PKMASK) || defined(WHVI_FUSED_SIGNED) || defined(WHVI_EXP_UNFUSED_DPP) || \
-    defined(WHVI_NO_PK) || defined(WHVI_BLOCK_TRACE) || defined(WHVI_VEC_AUX) || defined(WHVI_FUSED_UPFRONT_8THS) || defined(WHVI_ROWS_BUFFER_IO) || defined(WHVI_FUSED_TILE_LOADS) || defined(WHVI_F64_STREAM_FORM) || defined(WHVI_FUSED_SHARED_PLAIN_NT) || defined(WHVI_WBAR_FWD_STORE)
+    defined(WHVI_NO_PK) || defined(WHVI_BLOCK_TRACE) || defined(WHVI_VEC_AUX) || defined(WHVI_FUSED_UPFRONT_8THS) || defined(WHVI_ROWS_BUFFER_IO) || defined(WHVI_FUSED_TILE_LOADS) || defined(WHVI_F64_STREAM_FORM) || defined(WHVI_FUSED_SHARED_PLAIN_NT) || defined(WHVI_WIDE_TILE_WAVES) || defined(WHVI_WIDE_TILE_LOADS) || defined(WHVI_ALIGN_SINGLE_PASS) || defined(WHVI_WBAR_FWD_STORE)
 #error "kernel tuning switches need -DWHVI_TUNING_BUILD (make -C whvi_amd/csrc tuning DEFS=-D...)"
 #endif
 #endif
@@ -58,4 +58,13 @@
 #ifndef WHVI_FUSED_SHARED_PLAIN_NT
 #define WHVI_FUSED_SHARED_PLAIN_NT 1   // fused kernel on a shared (cache-resident) source = a write-dominated stream: non-temporal
                                        // stores without the write-through bit (0: the sc1 nt stores of the read + write streams)
+#endif
+#ifndef WHVI_WIDE_TILE_WAVES
+#define WHVI_WIDE_TILE_WAVES 0         // streaming launch of the f32 one-row tile of 128 data registers: waves per SIMD to compile for (0: the compiler's 2)
+#endif
+#ifndef WHVI_ALIGN_SINGLE_PASS
+#define WHVI_ALIGN_SINGLE_PASS -1      // store-barrier launches: -1 = tile loop run once for 16-bit storage, the grid-stride loop otherwise; 0 / 1 force
+#endif
+#ifndef WHVI_WIDE_TILE_LOADS
+#define WHVI_WIDE_TILE_LOADS 0         // streaming launch of 128-register tiles: 1 = bounds-checked buffer loads from the wave-uniform tile base, 0 = global loads
 #endif
