@@ -986,3 +986,34 @@ def test_integer_wrap_vectors_recorded_from_the_reference_gpu(hip_lib):
     for D in (64, 4096):
         got = _hip.fwht_rows(_t(g[f"wrap_i32_D{D}/in"])).cpu().numpy()
         assert np.array_equal(got, g[f"wrap_i32_D{D}/out"]), D
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_partial_tiles_never_touch_memory_beyond_the_buffers(dtype, hip_lib):
+    """The fused launch reaches a partial last tile (and every store) through bounds-checked buffer instructions whose
+    chunk offset rides in the instruction's SCALAR offset -- an operand LLVM documents as excluded from the bounds check.
+    On gfx950 the hardware check covers it; this test is what that claim rests on: source and destination are views in
+    the middle of larger buffers filled with sentinels, row counts end mid-tile, and not one sentinel byte on either side
+    of either buffer may change, in place and out of place."""
+    torch.manual_seed(5)
+    pad = 16384
+    for d in (4, 16, 64, 256, 512, 2048, 4096):
+        for rows in (1, 3, 5, 7, 33, 1000 // max(1, d // 64) + 1):
+            n = rows * d
+            big = torch.full((n + 2 * pad,), 12345.0, device=DEV, dtype=dtype)
+            src_big = torch.full((n + 2 * pad,), 777.0, device=DEV, dtype=dtype)
+            out, x = big[pad:pad + n].view(rows, d), src_big[pad:pad + n].view(rows, d)
+            x.copy_(torch.randn(rows, d, device=DEV, dtype=dtype))
+            a, c = (torch.randn(d, device=DEV, dtype=dtype) for _ in range(2))
+            b = torch.randn(1, d, device=DEV, dtype=dtype)
+            for in_place in (False, True):
+                if in_place:
+                    out.copy_(x)
+                    _hip.fused_shs(out, a, b, c, axis="col", n_samples=1, sample_stride=rows, out=out)
+                else:
+                    _hip.fused_shs(x, a, b, c, axis="col", n_samples=1, sample_stride=rows, out=out)
+                torch.cuda.synchronize()
+                assert bool((big[:pad] == 12345.0).all()) and bool((big[pad + n:] == 12345.0).all()), (d, rows, in_place)
+                assert bool((src_big[:pad] == 777.0).all()) and bool((src_big[pad + n:] == 777.0).all()), (d, rows, in_place)
+                assert bool(torch.isfinite(out).all())

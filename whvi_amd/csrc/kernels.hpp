@@ -340,7 +340,10 @@ fwht_rows_kernel(u32x4 *dst, const u32x4 *src, int64_t n_chunks, int64_t n_tiles
             for (int k = 0; k < K; ++k) raw[k] = uniform_ld16<NT>(src + base, bytes, lane, k * 1024);
         } else if (base + TILE <= n_chunks) {
 #pragma unroll
-            for (int k = 0; k < K; ++k) raw[k] = ld16<NT>(p + k * 64);
+            for (int k = 0; k < K; ++k) {
+                raw[k] = ld16<NT>(p + k * 64);
+                if constexpr (WHVI_ROWS_LOAD_SPACING > 0) asm volatile("s_nop %0" ::"n"(WHVI_ROWS_LOAD_SPACING - 1));   // A/B: issue spacing
+            }
         } else if constexpr (WIDE) {
             const uint32_t bytes = (uint32_t)((n_chunks - base) * 16);
 #pragma unroll
@@ -365,7 +368,22 @@ fwht_rows_kernel(u32x4 *dst, const u32x4 *src, int64_t n_chunks, int64_t n_tiles
 #pragma unroll
             for (int k = 0; k < K; ++k) uniform_st16<true>(dst + base, bytes, lane, k * 1024, E::pack(r[k]));
         } else if (base + TILE <= n_chunks) {
-            if constexpr (NT) {
+            if constexpr (NT && WHVI_ROWS_STORE_FORM == 1) {        // A/B: chunk offset as the instruction's scalar offset
+#pragma unroll
+                for (int k = 0; k < K; ++k) uniform_st16<true>(dst + base, TILE * 16, lane, k * 1024, E::pack(r[k]));
+            } else if constexpr (NT && WHVI_ROWS_STORE_FORM >= 3) {  // A/B: issue spacing between the stores
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    if constexpr (WHVI_ROWS_STORE_FORM == 5) uniform_st16<true>(dst + base, TILE * 16, lane, k * 1024, E::pack(r[k]));
+                    else tile_store_stream(dst + base, lane, k, E::pack(r[k]), TILE * 16);
+                    if constexpr (WHVI_ROWS_STORE_FORM == 4) __builtin_amdgcn_s_sleep(1);
+                    else if constexpr (WHVI_ROWS_STORE_FORM == 6) asm volatile("s_nop 0");
+                    else asm volatile("s_nop 7");
+                }
+            } else if constexpr (NT && WHVI_ROWS_STORE_FORM == 2) {  // A/B: descending chunk order
+#pragma unroll
+                for (int k = K - 1; k >= 0; --k) tile_store_stream(dst + base, lane, k, E::pack(r[k]), TILE * 16);
+            } else if constexpr (NT) {
 #pragma unroll
                 for (int k = 0; k < K; ++k) tile_store_stream(dst + base, lane, k, E::pack(r[k]), TILE * 16);
             } else {
@@ -386,9 +404,14 @@ fwht_rows_kernel(u32x4 *dst, const u32x4 *src, int64_t n_chunks, int64_t n_tiles
 #endif
     // Store-barrier launches are one tile per wave by construction (their block barriers would not survive a loop whose trip
     // count differs between the waves of a block).  Whether the CODE still contains the grid-stride loop decides nothing
-    // functionally and a lot in time -- measured, not explained (tools/probe_rows_forms.py, profiles/r03/rows_loop_form_ab.log):
-    // without it f32 / i32 / f64 LOSE 8-9 % (6.41 -> 5.90 TB/s at D = 512 .. 4096: same occupancy, same instruction mix, a
-    // different schedule), 16-bit storage GAINS: fp16 / bf16 D = 8192 5.5 / 5.3 -> 6.1-6.2 / 6.24, D <= 4096 +0.5 %.
+    // functionally and 9 % in time, through ONE thing (tools/probe_rows_forms.py, profiles/r03/rows_loop_form_ab.log,
+    // rows_store_issue_ab.log): how the 16 stores of a wave are ISSUED.  With the loop the compiler keeps one vector offset per
+    // chunk and computes it right in front of its store (v_or, store, v_or, store, ...); without it, it folds the chunk
+    // offsets into immediates and the stores go out back to back -- 6.45 -> 5.89 TB/s on the headline.  The same stores
+    // with a single s_nop between them: 6.44 (loop or no loop); with the chunk offset as the scalar offset and no spacing:
+    // 5.89, spaced: 6.42.  Loads want the opposite (an s_nop behind each: 6.21).  So: the 4- and 8-byte kernels keep the
+    // loop form; 16-bit storage (8 stores per wave, LDS-staged network) is compiled without it: fp16 / bf16 D = 8192
+    // 5.5 / 5.3 -> 6.1-6.2 / 6.24-6.36, D <= 4096 +0.5 %.
     constexpr bool SINGLE_PASS = ALIGN >= 1 && (WHVI_ALIGN_SINGLE_PASS == 1 || (WHVI_ALIGN_SINGLE_PASS < 0 && sizeof(T) == 2));
     if constexpr (!PREFETCH) {
         // plain grid-stride form: with grid == tiles/waves this is one tile per wave and out; only
@@ -1028,7 +1051,12 @@ fused_shs_kernel(u32x4 *dst, const u32x4 *src, const T *a, const T *b, const T *
     }
     if constexpr (NT) __syncthreads();          // the block's 4 waves write their 64 KiB back together
 #pragma unroll
-    for (int k = 0; k < K; ++k) uniform_st16<NT, !(SHARED_SRC && WHVI_FUSED_SHARED_PLAIN_NT)>(dst + base, tile_bytes, lane, k * 1024, E::pack(r[k]));
+    for (int k = 0; k < K; ++k) {
+        if constexpr (WHVI_FUSED_STORE_FORM == 1)        // A/B: the chunk offset in the VECTOR offset (one v_or per store)
+            uniform_st16<NT, !(SHARED_SRC && WHVI_FUSED_SHARED_PLAIN_NT)>(dst + base, tile_bytes, lane + k * 64, 0, E::pack(r[k]));
+        else
+            uniform_st16<NT, !(SHARED_SRC && WHVI_FUSED_SHARED_PLAIN_NT)>(dst + base, tile_bytes, lane, k * 1024, E::pack(r[k]));
+    }
 }
 
 // Rows shorter than one 16-byte chunk (D = 1, 2 for f32; D = 1 for f64): one thread per row, same

@@ -14,7 +14,7 @@
 #define WHVI_TUNE_ENV(name) ((const char *)nullptr)
 #if defined(WHVI_F16_UNPACK) || defined(WHVI_F16_PACK_EXP) || defined(WHVI_BF16_PACK) || defined(WHVI_ROWS_WAVES_PER_EU) || \
     defined(WHVI_ROWS_PKMASK) || defined(WHVI_FUSED_PKMASK) || defined(WHVI_FUSED_SIGNED) || defined(WHVI_EXP_UNFUSED_DPP) || \
-    defined(WHVI_NO_PK) || defined(WHVI_BLOCK_TRACE) || defined(WHVI_VEC_AUX) || defined(WHVI_FUSED_UPFRONT_8THS) || defined(WHVI_ROWS_BUFFER_IO) || defined(WHVI_FUSED_TILE_LOADS) || defined(WHVI_F64_STREAM_FORM) || defined(WHVI_FUSED_SHARED_PLAIN_NT) || defined(WHVI_WIDE_TILE_WAVES) || defined(WHVI_WIDE_TILE_LOADS) || defined(WHVI_ALIGN_SINGLE_PASS) || defined(WHVI_WBAR_FWD_STORE)
+    defined(WHVI_NO_PK) || defined(WHVI_BLOCK_TRACE) || defined(WHVI_VEC_AUX) || defined(WHVI_FUSED_UPFRONT_8THS) || defined(WHVI_ROWS_BUFFER_IO) || defined(WHVI_FUSED_TILE_LOADS) || defined(WHVI_F64_STREAM_FORM) || defined(WHVI_FUSED_SHARED_PLAIN_NT) || defined(WHVI_WIDE_TILE_WAVES) || defined(WHVI_FUSED_STORE_FORM) || defined(WHVI_ROWS_LOAD_SPACING) || defined(WHVI_ROWS_STORE_FORM) || defined(WHVI_WIDE_TILE_LOADS) || defined(WHVI_ALIGN_SINGLE_PASS) || defined(WHVI_WBAR_FWD_STORE)
 #error "kernel tuning switches need -DWHVI_TUNING_BUILD (make -C whvi_amd/csrc tuning DEFS=-D...)"
 #endif
 #endif
@@ -67,4 +67,13 @@
 #endif
 #ifndef WHVI_WIDE_TILE_LOADS
 #define WHVI_WIDE_TILE_LOADS 0         // streaming launch of 128-register tiles: 1 = bounds-checked buffer loads from the wave-uniform tile base, 0 = global loads
+#endif
+#ifndef WHVI_ROWS_STORE_FORM
+#define WHVI_ROWS_STORE_FORM 0         // streaming stores of the plain transform: 0 = one vector offset per chunk, 1 = scalar offsets, 2 = descending order (A/B)
+#endif
+#ifndef WHVI_FUSED_STORE_FORM
+#define WHVI_FUSED_STORE_FORM 0        // fused kernel stores: 0 = chunk offset as the scalar offset, 1 = in the vector offset (A/B)
+#endif
+#ifndef WHVI_ROWS_LOAD_SPACING
+#define WHVI_ROWS_LOAD_SPACING 0       // plain transform, full tiles: s_nop (N - 1) behind every tile load (A/B of issue spacing)
 #endif
