@@ -637,6 +637,7 @@ fwht_block_rows_kernel(u32x4 *dst, const u32x4 *src, int64_t n_rows, uint64_t *t
             constexpr int k = decltype(HALF)::value * (K / 2) + decltype(KK)::value;
             if constexpr (NT) tile_store_stream(tile, lane, k, E::pack(r[k]), TILE * 16);
             else tile[k * 64 + lane] = E::pack(r[k]);
+            if constexpr (NT && WHVI_STORE_SPACING) asm volatile("s_nop 0");     // stores never back to back (5.1, round 3)
         });
     };
     stamp(0);

@@ -131,6 +131,8 @@ wbar_fwd_kernel(u32x4 *dst, const T *s1, const T *u, const T *s2, const u32x4 *b
         for (int k = 0; k < K; ++k) tile_store_stream(dst + tile0, lane, k, E::pack(r[k]), TILE * 16);
     } else if (NT && full) {
 #pragma unroll
+        // (back to back: an s_nop between the stores -- which a read + write stream wants, DESIGN.md 5.1 round 3 -- costs a
+        // write-only stream 6-9 %: 6.24 vs 6.84 TB/s at D = 2048 x 256, 6.74 vs 7.27 at D = 4096 x 32)
         for (int k = 0; k < K; ++k) st16<(STORE_FORM == 2)>(dst + tile0 + k * 64 + lane, E::pack(r[k]));
     } else {
 #pragma unroll
