@@ -1051,6 +1051,17 @@ fused_shs_kernel(u32x4 *dst, const u32x4 *src, const T *a, const T *b, const T *
         else scale_chunkwise(a, a_per_sample);
     }
     if constexpr (NT) __syncthreads();          // the block's 4 waves write their 64 KiB back together
+    if constexpr (SHARED_SRC && NT && WHVI_FUSED_SHARED_GLOBAL_STORES) {
+        // A/B (measurement builds): the write-dominated launch on a shared, cache-resident source with back-to-back global
+        // stores like the write-only weight construction -- it LOSES (one transform per sample: 5.66 -> 5.25 TB/s written at
+        // D = 2048, 5.64 -> 5.32 at D = 512; two transforms: +-1 %), the spaced buffer stores below stay
+        if (tile_bytes == (uint32_t)(64 * K * 16)) {
+            u32x4 *q = dst + base + lane;
+#pragma unroll
+            for (int k = 0; k < K; ++k) st16<true>(q + k * 64, E::pack(r[k]));
+            return;
+        }
+    }
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         if constexpr (WHVI_FUSED_STORE_FORM == 1)        // A/B: the chunk offset in the VECTOR offset (one v_or per store)
