@@ -458,7 +458,7 @@ inline void launch_fused(void *dst, const void *src, const void *a, const void *
                 break;                                                                                  \
             }                                                                                           \
         }                                                                                               \
-        note_launch<T>("fused_shs_kernel", LOG2D, K, (int)AX, (bool)EYE, (bool)NT, (int)BLK, (int)POL, (int)STG); \
+        note_launch<T>("fused_shs_kernel", LOG2D, K, (int)AX, (bool)EYE, (bool)NT, (int)BLK, (int)POL, (int)STG, false, false); \
         constexpr size_t smem = ((POL == POLICY_LDS) ? (size_t)(BLK / 64) * slab_bytes : 0) +           \
                                 (((STG) == STAGE_ABC ? 3 : ((STG) == STAGE_AC ? 2 : 0)) * sizeof(typename Elem<T>::acc) << LOG2D); \
         if constexpr (smem > 64 * 1024)   /* per launch: the attribute belongs to the CURRENT device's copy */ \
