@@ -420,13 +420,16 @@ fwht_rows_kernel(u32x4 *dst, const u32x4 *src, int64_t n_chunks, int64_t n_tiles
             A r[K][VEC];
             {
                 u32x4 raw[K];
+                if constexpr (WHVI_ROWS_SETPRIO == 1) __builtin_amdgcn_s_setprio(3);      // A/B: loads issued at high priority
                 load_tile(t, raw);
+                if constexpr (WHVI_ROWS_SETPRIO == 1) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
                 for (int k = 0; k < K; ++k) E::unpack(raw[k], r[k]);
             }
             if constexpr (ALIGN >= 2) __syncthreads();
             transform(r);
             if constexpr (ALIGN >= 1) __syncthreads();
+            if constexpr (WHVI_ROWS_SETPRIO == 2) __builtin_amdgcn_s_setprio(3);          // A/B: stores issued at high priority
             // (Tried: a block barrier here so the 16 waves store their 256 KiB together.  A copy microbenchmark
             // gains 5 % from it, the real kernel LOSES 8 %: the waves leave the butterflies microseconds apart
             // and the barrier turns that skew into idle time.  profiles/r01/membench_6_store_alignment.log.)
