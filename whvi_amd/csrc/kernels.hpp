@@ -234,6 +234,15 @@ __device__ __forceinline__ u32x4 uniform_ld16(const void *base, uint32_t bytes, 
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
     return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, byte_offset, NT ? (1 << 1) : WHVI_VEC_AUX));
 }
+// the same load with the low 4 KiB of the byte offset in the instruction's immediate field and only the rest as the scalar
+// offset: consecutive chunks then share a scalar offset four at a time and issue back to back (no s_movk between them)
+template <bool NT = false>
+__device__ __forceinline__ u32x4 uniform_ld16_grouped(const void *base, uint32_t bytes, int lane, int byte_offset)
+{
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16 + (byte_offset & 4095), byte_offset & ~4095,
+                                                                            NT ? (1 << 1) : WHVI_VEC_AUX));
+}
 // the store counterpart; writes beyond `bytes` are dropped.  NT: write-through + non-temporal (see tile_store_stream)
 template <bool NT, bool WRITE_THROUGH = true>
 __device__ __forceinline__ void uniform_st16(void *base, uint32_t bytes, int lane, int byte_offset, const u32x4 &v)
@@ -879,7 +888,12 @@ fused_shs_kernel(u32x4 *dst, const u32x4 *src, const T *a, const T *b, const T *
 #endif
         {
 #pragma unroll
-            for (int k = 0; k < K; ++k) raw[k] = uniform_ld16<NT>(src + base, tile_bytes, lane, k * 1024);
+            for (int k = 0; k < K; ++k) {
+                if constexpr (WHVI_FUSED_TILE_LOADS_GROUPED == 1 || (WHVI_FUSED_TILE_LOADS_GROUPED < 0 && sizeof(T) == 8))
+                    raw[k] = uniform_ld16_grouped<NT>(src + base, tile_bytes, lane, k * 1024);      // four per scalar offset: back to back
+                else
+                    raw[k] = uniform_ld16<NT>(src + base, tile_bytes, lane, k * 1024);
+            }
         }
     }
     if constexpr (STAGE != STAGE_NONE) {
@@ -937,8 +951,15 @@ fused_shs_kernel(u32x4 *dst, const u32x4 *src, const T *a, const T *b, const T *
     };
     auto scale = [&](const T *vec, bool per_sample, const RowBases &rb, int k, A (&out)[VEC]) {
         if constexpr (UNIFORM) {
-            E::unpack(uniform_ld16(rb.p[k / CHUNKS_PER_ROW_HERE], (uint32_t)sizeof(T) << LOG2D, lane,
-                                   (k % CHUNKS_PER_ROW_HERE) * 1024), out);
+            // f64: four loads per scalar offset (the low 3 KiB of the chunk offset as immediates), so the loads of a vector
+            // issue back to back instead of one s_movk apart: f64 D = 4096 shared 5.88 -> 6.02 TB/s, per-sample D <= 2048
+            // +1 %; f32 +-0.2 % either way (profiles/r03/fused_vector_load_issue_ab.log) and keeps the plain form
+            if constexpr (WHVI_VEC_LOAD_GROUPED == 1 || (WHVI_VEC_LOAD_GROUPED < 0 && sizeof(T) == 8))
+                E::unpack(uniform_ld16_grouped(rb.p[k / CHUNKS_PER_ROW_HERE], (uint32_t)sizeof(T) << LOG2D, lane,
+                                               (k % CHUNKS_PER_ROW_HERE) * 1024), out);
+            else
+                E::unpack(uniform_ld16(rb.p[k / CHUNKS_PER_ROW_HERE], (uint32_t)sizeof(T) << LOG2D, lane,
+                                       (k % CHUNKS_PER_ROW_HERE) * 1024), out);
         } else if constexpr (AXIS == WHVI_AXIS_COL) {
             const uint32_t vec_base = per_sample ? sample_index(chunk_row(k)) << LOG2D : 0u;
             E::unpack(*reinterpret_cast<const u32x4 *>(vec + (size_t)vec_base + chunk_col(k) * VEC), out);

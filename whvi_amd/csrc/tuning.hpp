@@ -14,7 +14,7 @@
 #define WHVI_TUNE_ENV(name) ((const char *)nullptr)
 #if defined(WHVI_F16_UNPACK) || defined(WHVI_F16_PACK_EXP) || defined(WHVI_BF16_PACK) || defined(WHVI_ROWS_WAVES_PER_EU) || \
     defined(WHVI_ROWS_PKMASK) || defined(WHVI_FUSED_PKMASK) || defined(WHVI_FUSED_SIGNED) || defined(WHVI_EXP_UNFUSED_DPP) || \
-    defined(WHVI_NO_PK) || defined(WHVI_BLOCK_TRACE) || defined(WHVI_VEC_AUX) || defined(WHVI_FUSED_UPFRONT_8THS) || defined(WHVI_ROWS_BUFFER_IO) || defined(WHVI_FUSED_TILE_LOADS) || defined(WHVI_F64_STREAM_FORM) || defined(WHVI_FUSED_SHARED_PLAIN_NT) || defined(WHVI_WIDE_TILE_WAVES) || defined(WHVI_ROWS_SETPRIO) || defined(WHVI_FUSED_SHARED_GLOBAL_STORES) || defined(WHVI_STORE_SPACING) || defined(WHVI_FUSED_STORE_FORM) || defined(WHVI_ROWS_LOAD_SPACING) || defined(WHVI_ROWS_STORE_FORM) || defined(WHVI_WIDE_TILE_LOADS) || defined(WHVI_ALIGN_SINGLE_PASS) || defined(WHVI_WBAR_FWD_STORE)
+    defined(WHVI_NO_PK) || defined(WHVI_BLOCK_TRACE) || defined(WHVI_VEC_AUX) || defined(WHVI_FUSED_UPFRONT_8THS) || defined(WHVI_ROWS_BUFFER_IO) || defined(WHVI_FUSED_TILE_LOADS) || defined(WHVI_F64_STREAM_FORM) || defined(WHVI_FUSED_SHARED_PLAIN_NT) || defined(WHVI_WIDE_TILE_WAVES) || defined(WHVI_FUSED_TILE_LOADS_GROUPED) || defined(WHVI_VEC_LOAD_GROUPED) || defined(WHVI_ROWS_SETPRIO) || defined(WHVI_FUSED_SHARED_GLOBAL_STORES) || defined(WHVI_STORE_SPACING) || defined(WHVI_FUSED_STORE_FORM) || defined(WHVI_ROWS_LOAD_SPACING) || defined(WHVI_ROWS_STORE_FORM) || defined(WHVI_WIDE_TILE_LOADS) || defined(WHVI_ALIGN_SINGLE_PASS) || defined(WHVI_WBAR_FWD_STORE)
 #error "kernel tuning switches need -DWHVI_TUNING_BUILD (make -C whvi_amd/csrc tuning DEFS=-D...)"
 #endif
 #endif
@@ -85,4 +85,10 @@
 #endif
 #ifndef WHVI_ROWS_SETPRIO
 #define WHVI_ROWS_SETPRIO 0            // plain transform: 1 = s_setprio 3 around the tile loads, 2 = from the store barrier on (A/B)
+#endif
+#ifndef WHVI_VEC_LOAD_GROUPED
+#define WHVI_VEC_LOAD_GROUPED -1       // fused kernel, L2-sourced scale vectors: four loads per scalar offset, issued back to back: -1 = f64 only, 0 / 1 force
+#endif
+#ifndef WHVI_FUSED_TILE_LOADS_GROUPED
+#define WHVI_FUSED_TILE_LOADS_GROUPED 0   // fused kernel, tile loads through buffer instructions: four loads per scalar offset: -1 = f64 only, 0 / 1 force
 #endif
