@@ -293,6 +293,23 @@ fwht_rows_kernel(u32x4 *dst, const u32x4 *src, int64_t n_chunks, int64_t n_tiles
         if constexpr (ALIGN >= 1) __syncthreads();
         return;
     }
+    // Store-barrier launches are one tile per wave by construction (their block barriers would not survive a loop whose trip
+    // count differs between the waves of a block).  Whether the CODE still contains the grid-stride loop decides nothing
+    // functionally and 9 % in time, through ONE thing (tools/probe_rows_forms.py, profiles/r03/rows_loop_form_ab.log,
+    // rows_store_issue_ab.log): how the 16 stores of a wave are ISSUED.  With the loop the compiler keeps one vector offset per
+    // chunk and computes it right in front of its store (v_or, store, v_or, store, ...); without it, it folds the chunk
+    // offsets into immediates and the stores go out back to back -- 6.45 -> 5.89 TB/s on the headline.  The same stores
+    // with a single s_nop between them: 6.44 (loop or no loop); with the chunk offset as the scalar offset and no spacing:
+    // 5.89, spaced: 6.42.  Loads want the opposite (an s_nop behind each: 6.21).  So: the 4- and 8-byte kernels keep the
+    // loop form; 16-bit storage (8 stores per wave, LDS-staged network) is compiled without it: fp16 / bf16 D = 8192
+    // 5.5 / 5.3 -> 6.1-6.2 / 6.24-6.36, D <= 4096 +0.5 %.
+    // Per-type table of the loop-less form WITH an explicit s_nop between the stores (rows_store_issue_ab.log): f64 D <= 2048
+    // +1 % (6.32 -> 6.39), the 128-register f32 / i32 tiles +3 % / +1 % (5.60 -> 5.79, 6.36 -> 6.43); f32 / i32 D <= 4096 and
+    // f64 D = 4096 lose 0-4 % and keep the loop.
+    constexpr bool WIDE4 = K * VEC * (int)sizeof(A) / 4 > 64 && sizeof(T) == 4;
+    constexpr bool AUTO_SINGLE = sizeof(T) == 2 || (WHVI_ALIGN_SINGLE_PASS == -1 && ((sizeof(T) == 8 && LOG2D <= 11) || WIDE4));
+    constexpr bool SINGLE_PASS = ALIGN >= 1 && (WHVI_ALIGN_SINGLE_PASS == 1 || (WHVI_ALIGN_SINGLE_PASS < 0 && AUTO_SINGLE));
+    constexpr bool STORE_NOP = SINGLE_PASS && sizeof(T) != 2;          // the loop-less code issues its stores back to back
     extern __shared__ __attribute__((aligned(16))) char whvi_smem[];
     auto transform = [&](A (&r)[K][VEC]) {
         if constexpr (POLICY == POLICY_LDS)
@@ -394,7 +411,10 @@ fwht_rows_kernel(u32x4 *dst, const u32x4 *src, int64_t n_chunks, int64_t n_tiles
                 for (int k = K - 1; k >= 0; --k) tile_store_stream(dst + base, lane, k, E::pack(r[k]), TILE * 16);
             } else if constexpr (NT) {
 #pragma unroll
-                for (int k = 0; k < K; ++k) tile_store_stream(dst + base, lane, k, E::pack(r[k]), TILE * 16);
+                for (int k = 0; k < K; ++k) {
+                    tile_store_stream(dst + base, lane, k, E::pack(r[k]), TILE * 16);
+                    if constexpr (STORE_NOP) asm volatile("s_nop 0");
+                }
             } else {
 #pragma unroll
                 for (int k = 0; k < K; ++k) st16<NT>(q + k * 64, E::pack(r[k]));
@@ -411,17 +431,6 @@ fwht_rows_kernel(u32x4 *dst, const u32x4 *src, int64_t n_chunks, int64_t n_tiles
     };
 
 #endif
-    // Store-barrier launches are one tile per wave by construction (their block barriers would not survive a loop whose trip
-    // count differs between the waves of a block).  Whether the CODE still contains the grid-stride loop decides nothing
-    // functionally and 9 % in time, through ONE thing (tools/probe_rows_forms.py, profiles/r03/rows_loop_form_ab.log,
-    // rows_store_issue_ab.log): how the 16 stores of a wave are ISSUED.  With the loop the compiler keeps one vector offset per
-    // chunk and computes it right in front of its store (v_or, store, v_or, store, ...); without it, it folds the chunk
-    // offsets into immediates and the stores go out back to back -- 6.45 -> 5.89 TB/s on the headline.  The same stores
-    // with a single s_nop between them: 6.44 (loop or no loop); with the chunk offset as the scalar offset and no spacing:
-    // 5.89, spaced: 6.42.  Loads want the opposite (an s_nop behind each: 6.21).  So: the 4- and 8-byte kernels keep the
-    // loop form; 16-bit storage (8 stores per wave, LDS-staged network) is compiled without it: fp16 / bf16 D = 8192
-    // 5.5 / 5.3 -> 6.1-6.2 / 6.24-6.36, D <= 4096 +0.5 %.
-    constexpr bool SINGLE_PASS = ALIGN >= 1 && (WHVI_ALIGN_SINGLE_PASS == 1 || (WHVI_ALIGN_SINGLE_PASS < 0 && sizeof(T) == 2));
     if constexpr (!PREFETCH) {
         // plain grid-stride form: with grid == tiles/waves this is one tile per wave and out; only
         // one tile's worth of registers is ever live (fits a 1024-thread block at 128 VGPRs)

@@ -63,7 +63,7 @@
 #define WHVI_WIDE_TILE_WAVES 0         // streaming launch of the f32 one-row tile of 128 data registers: waves per SIMD to compile for (0: the compiler's 2)
 #endif
 #ifndef WHVI_ALIGN_SINGLE_PASS
-#define WHVI_ALIGN_SINGLE_PASS -1      // store-barrier launches: -1 = tile loop run once for 16-bit storage, the grid-stride loop otherwise; 0 / 1 force
+#define WHVI_ALIGN_SINGLE_PASS -1      // store-barrier launches without the tile loop in the code: -1 = per-type rule (kernels.hpp), -2 = 16-bit storage only, 0 / 1 force
 #endif
 #ifndef WHVI_WIDE_TILE_LOADS
 #define WHVI_WIDE_TILE_LOADS 0         // streaming launch of 128-register tiles: 1 = bounds-checked buffer loads from the wave-uniform tile base, 0 = global loads
