@@ -12,12 +12,12 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "whvi_amd", "csrc")
 UNITS = ["fwht_f32", "fwht_f64", "fwht_f16", "fwht_bf16", "fwht_i32", "fused_f32", "fused_f64", "wbar_bwd_f32",
-         "wbar_bwd_f64", "wbar_fwd_f32", "wbar_fwd_f64", "train_aux", "abi"]
+         "wbar_bwd_f64", "wbar_fwd_f32", "wbar_fwd_f64", "train_aux", "abi", "fwht_wide"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden",
          "-Rpass-analysis=kernel-resource-usage", "-c", "-o", "/dev/null"]
 
 
-EXTRA = {"fused_f32": ["-fno-slp-vectorize"]}      # per-unit flags, as in whvi_amd/csrc/Makefile
+EXTRA = {"fused_f32": ["-fno-slp-vectorize"], "fwht_wide": ["-fno-slp-vectorize"]}      # per-unit flags, as in whvi_amd/csrc/Makefile
 
 
 def scan(unit):

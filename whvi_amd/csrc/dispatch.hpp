@@ -133,6 +133,13 @@ inline bool stream_sized(int64_t bytes, const void *dst, const void *src)
     return (dst == src || src == nullptr ? bytes : 2 * bytes) > NT_MIN_BYTES;
 }
 
+// Streaming launch of the f32 one-row tile of 128 data registers (D = 8192) at THREE waves per SIMD.  Defined -- with its
+// kernel -- in fwht_wide.hip, a translation unit compiled with -fno-slp-vectorize: at 168 VGPRs the even-aligned register
+// pairs of the packed adds the SLP vectoriser forms are what does not fit (with them: 28-120 B / lane of scratch; without:
+// none).  The 64-register tiles WANT those pairs (6.46 vs 6.30 TB/s, 5.1), so they stay in fwht_f32.hip.
+template <typename T>
+void launch_wide_stream(u32x4 *d, const u32x4 *s, int64_t n_chunks, int64_t n_tiles, hipStream_t st);
+
 // variant word of whvi_fwht_ex: documented in include/whvi_hip.h (0 = production launch).
 // FULL = the extra tuning variants are compiled (f32, D = 512..4096).
 template <typename T, int LOG2D, int K, bool FULL>
@@ -202,9 +209,13 @@ inline void launch_rows(void *dst, const void *src, int64_t n_chunks, int varian
             // either way; streams get the non-temporal accesses and the store barrier as well
             if (big && nt) {
                 constexpr bool SG = (sizeof(T) == 8 || std::is_same<T, float>::value) && WHVI_F64_STREAM_FORM == 3;   // tuning: the signed network here loses (6.23 vs 6.31)
-                note_launch<T>("fwht_rows_kernel", LOG2D, K, POLICY_DPP, false, true, 256, 1, SG);
-                hipLaunchKernelGGL((fwht_rows_kernel<T, LOG2D, K, POLICY_DPP, false, true, 256, 1, SG>),
-                                   dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, st, d, s, n_chunks, n_tiles);
+                if constexpr (!SG && std::is_same<T, float>::value && LOG2D == max_single_pass_log2d<T>() && WHVI_WIDE_TILE_WAVES > 0)
+                    launch_wide_stream<T>(d, s, n_chunks, n_tiles, st);
+                else {
+                    note_launch<T>("fwht_rows_kernel", LOG2D, K, POLICY_DPP, false, true, 256, 1, SG);
+                    hipLaunchKernelGGL((fwht_rows_kernel<T, LOG2D, K, POLICY_DPP, false, true, 256, 1, SG>),
+                                       dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, st, d, s, n_chunks, n_tiles);
+                }
             } else WHVI_LAUNCH(POLICY_DPP, false, false, 256);
         }
         return;

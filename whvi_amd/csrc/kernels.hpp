@@ -252,10 +252,12 @@ __device__ __forceinline__ void uniform_st16(void *base, uint32_t bytes, int lan
 }
 
 // Occupancy target of fwht_rows_kernel.  One-row tiles of 128 data registers (f32 / i32 D = 8192, f64 D = 4096) are
-// compiled to 241 VGPRs = two waves per SIMD when left alone.  Round 3 measured the f32 one at THREE (168 VGPRs, measurement
-// builds -DWHVI_WIDE_TILE_WAVES=3): 5.50 -> 6.09 TB/s -- with 120 B / lane of scratch.  No spill-free form kept the gain
-// (partial tiles through buffer accesses, chunk offsets as scalar offsets, no SLP pairs, the tile loop run once: 0-28 B of
-// scratch, 5.4-5.6 TB/s), so under the no-scratch rule (tools/check_spills.py) the shipped kernel stays at two waves.
+// compiled to 241 VGPRs = two waves per SIMD when left alone.  The f32 one is co-limited by its VALU work (the i32 instance of
+// the same kernel, without sign folds, streams at 6.4 TB/s; f32 at 5.6-5.8) and gains from a THIRD wave: 168 VGPRs without
+// scratch take (a) its partial tile through bounds-checked buffer accesses and its stores with the chunk offset as the
+// scalar offset (no per-chunk address pairs / vector offsets), (b) no tile loop in the code, (c) no SLP register pairs --
+// hence its own translation unit, fwht_wide.hip.  5.79 -> 6.07 TB/s (with scratch and the loop: 6.09; profiles/r03/
+// rows_store_issue_ab.log).  f64 D = 4096 gains nothing from a third wave (5.88 vs 5.91), i32 needs none.
 template <typename T, int K, int ALIGN> constexpr int rows_waves_per_eu()
 {
     // (f32 only: f64 gains nothing from the third wave, 5.88 vs 5.91 TB/s)
@@ -355,7 +357,7 @@ fwht_rows_kernel(u32x4 *dst, const u32x4 *src, int64_t n_chunks, int64_t n_tiles
     // One-row tiles of 128 data registers: the partial last tile goes through bounds-checked buffer accesses from the
     // tile's wave-uniform base (reads beyond the buffer return zeros, writes are dropped) instead of 32 guarded accesses
     // with a 64-bit compare and an address pair each -- registers the 168-VGPR budget of three waves per SIMD does not have.
-    constexpr bool WIDE = K * VEC * (int)sizeof(A) / 4 > 64 && WHVI_WIDE_TILE_WAVES > 0;      // measurement builds only, see rows_waves_per_eu
+    constexpr bool WIDE = K * VEC * (int)sizeof(A) / 4 > 64 && WHVI_WIDE_TILE_WAVES > 0 && std::is_same<T, float>::value;   // the 3-wave f32 tile, see rows_waves_per_eu
     auto load_tile = [&](int64_t tile, u32x4 (&raw)[K]) {
         const int64_t base = tile * TILE;
         const u32x4 *p = src + base + lane;

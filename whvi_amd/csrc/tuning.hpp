@@ -60,7 +60,7 @@
                                        // stores without the write-through bit (0: the sc1 nt stores of the read + write streams)
 #endif
 #ifndef WHVI_WIDE_TILE_WAVES
-#define WHVI_WIDE_TILE_WAVES 0         // streaming launch of the f32 one-row tile of 128 data registers: waves per SIMD to compile for (0: the compiler's 2)
+#define WHVI_WIDE_TILE_WAVES 3         // streaming launch of the f32 one-row tile of 128 data registers: waves per SIMD to compile for (0: the compiler's 2, in fwht_f32.hip)
 #endif
 #ifndef WHVI_ALIGN_SINGLE_PASS
 #define WHVI_ALIGN_SINGLE_PASS -1      // store-barrier launches without the tile loop in the code: -1 = per-type rule (kernels.hpp), -2 = 16-bit storage only, 0 / 1 force
