@@ -516,3 +516,41 @@ def test_negative_zero_contract_of_both_launch_forms(hip_lib):
     other = torch.ones(16, dtype=torch.bool)
     other[7] = False
     assert torch.equal(big[:16][other.to(DEV)].view(torch.int32), small[other.to(DEV)].view(torch.int32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,log2d,K", [(torch.float32, 13, 32), (torch.int32, 13, 32), (torch.float64, 12, 32),
+                                           (torch.float16, 13, 16), (torch.bfloat16, 13, 16)])
+def test_one_row_tiles_of_128_registers_at_streaming_size(dtype, log2d, K, hip_lib):
+    """The widest single-wave rows (f32 / i32 / fp16 / bf16 D = 8192, f64 D = 4096: 128 accumulator registers per lane) as
+    STREAMS of 320 MiB with a partial last block -- for f32 the three-waves-per-SIMD kernel of fwht_wide.hip, whose stores
+    carry the chunk offset as the scalar offset of a bounds-checked buffer instruction: sampled
+    rows bit for bit against the oracle, in place == out of place, H.H = D.I on small integers, the launched symbol, and
+    not one byte touched beyond either end of the buffer (the tensor sits in the middle of a sentinel-filled allocation)."""
+    d = 1 << log2d
+    esize = torch.empty(0, dtype=dtype).element_size()
+    rows = ((320 << 20) // (esize * d)) | 1                     # odd: one tile = one row, so the last BLOCK has idle waves
+    pad = 4 * d
+    g = torch.Generator(device=DEV).manual_seed(log2d + esize)
+    ints = torch.randint(-3, 4, (rows, d), device=DEV, generator=g, dtype=torch.int32)
+    big = torch.full((rows * d + 2 * pad,), 7, device=DEV, dtype=dtype)
+    x = big[pad:pad + rows * d].view(rows, d)
+    x.copy_(ints.to(dtype) if dtype == torch.int32 else (torch.randn(rows, d, device=DEV, generator=g) * 0.25).to(dtype))
+    idx = torch.cat((torch.tensor([0, 1, 2, 3, rows // 2, rows - 2, rows - 1]), torch.randint(0, rows, (57,)))).to(DEV)
+    keep = x[idx].clone()
+    out = _hip.fwht_rows(x)                                      # out of place
+    name = {torch.float32: "float", torch.int32: "int", torch.float64: "double", torch.float16: "__half",
+            torch.bfloat16: "__hip_bfloat16"}[dtype]
+    assert _hip.last_kernel() == f"whvi::fwht_rows_kernel<{name}, {log2d}, {K}, 0, false, true, 256, 1, false>", _hip.last_kernel()
+    _hip.fwht_rows(x, out=x)                                     # in place
+    assert torch.equal(x.view(torch.uint8), out.view(torch.uint8))
+    assert torch.equal(x[idx].cpu().view(torch.uint8), _oracle(keep.cpu()).view(torch.uint8))
+    sentinel = torch.full((pad,), 7, device=DEV, dtype=dtype)
+    assert torch.equal(big[:pad].view(torch.uint8), sentinel.view(torch.uint8))
+    assert torch.equal(big[pad + rows * d:].view(torch.uint8), sentinel.view(torch.uint8))
+    if dtype in (torch.int32, torch.float64):                    # exact there at any magnitude the sums reach: an involution up to D
+        x.copy_(ints.to(dtype))
+        _hip.fwht_rows(x, out=x)
+        _hip.fwht_rows(x, out=x)
+        assert torch.equal(x[idx].to(torch.int64), ints[idx].to(torch.int64) * d)
+        assert torch.equal(x[-1].to(torch.int64), ints[-1].to(torch.int64) * d)
