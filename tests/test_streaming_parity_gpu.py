@@ -232,3 +232,56 @@ def test_shared_source_equals_the_expanded_launch(dtype, log2d, B, hip_lib):
         _hip.fused_shs(x, a, b, c, axis="col", n_samples=S, sample_stride=B, one_transform=True)
     with pytest.raises(RuntimeError, match="src_shared needs"):
         _hip.fused_shs(torch.zeros(4, 64, device=DEV), a[:64], b[:, :64], c[:64], axis="col", n_samples=S, sample_stride=4, src_shared=True)
+
+
+@pytest.mark.parametrize("one", [False, True])
+@pytest.mark.parametrize("dtype,log2d,S,B", [(torch.float32, 11, 64, 256),     # S > the 32 blocks per sample
+                                             (torch.float32, 12, 10, 1024),    # S does not divide the 256 blocks per sample
+                                             (torch.float32, 11, 80, 256),     # not a power of two, > the 32 blocks per sample
+                                             (torch.float64, 12, 300, 32),     # one 128-register row per tile
+                                             (torch.float32, 9, 36, 2048)])    # 32 rows per block
+def test_shared_source_with_per_sample_outer_vectors(dtype, log2d, S, B, one, hip_lib):
+    """WHVI_FUSED_SRC_SHARED together with per-sample a / c on launches big enough for the tuned dispatch (>= 32 tiles per
+    CU; shared-source block order "sample fastest within an XCD", a / c of the block's ONE sample staged in LDS).  Round 3
+    shipped a block map that put the four waves of such a block into different samples whenever S did not divide the
+    blocks per sample while staging wave 0's vectors only (kernels.hpp) -- no test had this flag combination.
+    Sampled rows bit for bit against ``oracle.pipeline(a_per_sample, c_per_sample)`` (matmul_diag_right . fwht chains of
+    src/utils.py:15-23 + src/fwht/cpp/fwht.cpp:7-18) and the whole result against the expanded-input launch."""
+    d = 1 << log2d
+    g = torch.Generator(device=DEV).manual_seed(log2d * 977 + S * 13 + B)
+    x = torch.randn(B, d, device=DEV, dtype=dtype, generator=g)
+    a = torch.randn(S, d, device=DEV, dtype=dtype, generator=g) * 0.1
+    c = torch.randn(S, d, device=DEV, dtype=dtype, generator=g) * 0.1
+    b = torch.randn(S, d, device=DEV, dtype=dtype, generator=g)
+    rows = S * B
+    props = torch.cuda.get_device_properties(0)
+    k_rows = 1 if (dtype == torch.float64 and log2d == 12) else max(1, (16384 // x.element_size()) // d)   # rows per tile
+    n_tiles = rows // k_rows
+    assert n_tiles >= (16 if k_rows == 1 and dtype == torch.float64 else 32) * props.multi_processor_count, "not the tuned dispatch"
+    if one:
+        got = _hip.fused_shs(x, a, b, None, axis="col", n_samples=S, sample_stride=B, src_shared=True, one_transform=True,
+                             a_per_sample=True)
+        assert _hip.last_kernel().endswith(", 1, true, true>"), _hip.last_kernel()          # a staged per block
+    else:
+        got = _hip.fused_shs(x, a, b, c, axis="col", n_samples=S, sample_stride=B, src_shared=True, a_per_sample=True,
+                             c_per_sample=True)
+        assert _hip.last_kernel().endswith(", 1, true, false>"), _hip.last_kernel()
+    rng = np.random.default_rng(S * B)
+    idx = np.unique(np.clip(np.concatenate([[0, 1, B - 1, B, B + 1, 2 * B - 1, rows - B, rows - 1],
+                                            rng.integers(0, rows, 150)]), 0, rows - 1))
+    smp = idx // B
+    an, bn, cn = a.cpu().numpy(), b.cpu().numpy(), c.cpu().numpy()
+    xs = x[torch.from_numpy(idx % B).to(DEV)].cpu().numpy()
+    if one:      # a_s (.) FWHT(b_s (.) x): the pipeline with c = 1 and an identity first transform has no oracle form;
+        want = an[smp] * oracle.fwht(bn[smp] * xs)                                         # compose it from the parts
+    else:
+        want = oracle.pipeline(xs, an[smp], bn[smp], cn[smp], n_samples=len(idx), sample_stride=1, axis="col",
+                               a_per_sample=True, c_per_sample=True)
+    assert np.array_equal(_bits(got[torch.from_numpy(idx).to(DEV)].cpu().numpy()), _bits(want))
+    if one:
+        expanded = _hip.fused_shs(x.repeat(S, 1), a, b, None, axis="col", n_samples=S, sample_stride=B, one_transform=True,
+                                  a_per_sample=True)
+    else:
+        expanded = _hip.fused_shs(x.repeat(S, 1), a, b, c, axis="col", n_samples=S, sample_stride=B, a_per_sample=True,
+                                  c_per_sample=True)
+    assert torch.equal(got.view(torch.uint8), expanded.view(torch.uint8))

@@ -814,7 +814,10 @@ fused_shs_kernel(u32x4 *dst, const u32x4 *src, const T *a, const T *b, const T *
     // can be staged once per block like shared ones instead of three vectors per tile coming through L2 (where at 16 KiB
     // per vector and 64 samples they no longer all stay: +14 % fabric reads, profiles/r03).  Consecutive blocks take
     // consecutive s: a group of S blocks still covers 4 S contiguous rows.
-    if (same_sample_blocks != 0u) {
+    // (mode 1 ONLY: under mode 2 -- the shared-source order above -- a block keeps four CONSECUTIVE tiles, which the host
+    // has checked lie inside one sample; taking this branch there as well put the waves S tiles apart, i.e. in different
+    // samples whenever S does not divide the blocks per sample, while wave 0's sample alone was staged: round-3 bug)
+    if (same_sample_blocks == 1u) {
         const uint32_t q = by_n_samples.div((uint32_t)blk), smp = (uint32_t)blk - q * by_n_samples.d;
         t = ((int64_t)q * (BLOCK / 64) + wave) * by_n_samples.d + smp;
     }
@@ -845,7 +848,7 @@ fused_shs_kernel(u32x4 *dst, const u32x4 *src, const T *a, const T *b, const T *
     A *const stg_dst[3] = {lds_c, lds_a, lds_b};
     if constexpr (STAGE != STAGE_NONE) {
         // the block's sample: read only where a vector is per-sample (all rows of the block then share it: host-checked)
-        const int64_t t_first = same_sample_blocks != 0u ? t - (int64_t)wave * by_n_samples.d : blk * (BLOCK / 64);   // wave 0's tile
+        const int64_t t_first = same_sample_blocks == 1u ? t - (int64_t)wave * by_n_samples.d : blk * (BLOCK / 64);   // wave 0's tile
         const uint32_t blk_row0 = (uint32_t)((t_first * TILE) >> SH);
         const size_t s_off = (size_t)sample_index(blk_row0) << LOG2D;
         stg_src[0] = (c == nullptr || ONE) ? nullptr : c + (c_per_sample ? s_off : 0);
