@@ -247,6 +247,47 @@ int whvi_wbar_bwd_f64(void *grad_u, void *part_s1, void *part_s2, const void *gr
                       const void *u, const void *s2, int64_t J, int64_t S, int64_t R, int32_t log2d,
                       int32_t flags, void *stream);
 
+/* `h @ (w_bar(g_mu) + w_bar(g_sigma * eps_k)).T (+ bias)` of src/weights.py:87-93,101-102 for all MC samples in ONE launch,
+ * without building the matrices.  As written in the reference w_bar(u) = S1 . fwht(diag(u) . fwht(diag(s2))) is EXACTLY
+ * D * diag(s1 (.) u (.) s2) -- row scales around row transforms, SURVEY.md finding 1 -- so the dense product adds exact zeros
+ * to one product per output.  This entry computes that product directly, with the roundings of the as-written chain in the
+ * same order ( v = u_i * s2_i;  D * v exact;  s1_i * .;  mean + sample;  h * w;  + bias ):
+ *     out[k, b, i] = x[(k,) b, i] * ( wd(u[0])_i + wd(u[1 + k])_i ) + bias[i],     wd(u)_i = s1_i * (D * (u_i * s2_i)),
+ * value-identical to the matrix route (weight construction + GEMM) for every input; the sign of a ZERO result is the
+ * product's, where the GEMM's sum of D signed zeros usually gives +0.  Non-finite operands are propagated as the matrix
+ * route propagates them: a row of x holding an inf / NaN at column j makes every other output of that row NaN (inf * 0 in
+ * the dot product), a non-finite s1_i or an overflowing partial sum of the second transform (|D/2 * u_i * s2_i| = inf) makes
+ * output column i NaN.
+ *   x    : (S, B, D), or (B, D) with WHVI_DIAG_X_SHARED (a layer's first pass: one input for all samples; dst must not overlap)
+ *   u    : (1 + S, D) with WHVI_DIAG_MEAN_PLUS (row 0 = g_mu, row 1 + k = g_sigma * eps_k: the buffer whvi_reparam_kl
+ *          writes), else (S, D) and w_k = wd(u[k]) alone (direct weight sampling, src/weights.py:75-85,104-108)
+ *   s1, s2 : (D,)    bias : (D,) or NULL    out : (S, B, D); out == x is allowed without WHVI_DIAG_X_SHARED
+ *   log2d in [2, 12] (f32) / [1, 11] (f64). */
+#define WHVI_DIAG_X_SHARED  1
+#define WHVI_DIAG_MEAN_PLUS 2
+int whvi_diag_apply_f32(void *out, const void *x, const void *s1, const void *s2, const void *u, const void *bias,
+                        int64_t S, int64_t B, int32_t log2d, int32_t flags, void *stream);
+int whvi_diag_apply_f64(void *out, const void *x, const void *s1, const void *s2, const void *u, const void *bias,
+                        int64_t S, int64_t B, int32_t log2d, int32_t flags, void *stream);
+
+/* Backward of whvi_diag_apply (closed form; replaces autograd over the GEMM, the weight construction and its op chain):
+ *   grad_x : (S, B, D) = g[k, b, :] (.) w_k, or NULL when the input needs no gradient (with WHVI_DIAG_X_SHARED the caller
+ *            sums it over k)
+ *   out    : (4, U, D), U = S (+ 1 with WHVI_DIAG_MEAN_PLUS); row r = k (+ 1) of slot 0 = dL/du[r], of slots 1 / 2 = sample
+ *            k's share of dL/ds1 / dL/ds2, of slot 3 = its share of dL/dbias = sum_b g[k, b, :].  With the mean row, row 0
+ *            is left to the caller: the sum of rows 1 .. S is dL/du[0] resp. the totals (one reduction for all four).
+ *   part   : workspace of S * n_slabs * 2 * D elements, n_slabs = whvi_diag_apply_bwd_slabs(dtype, S, B, log2d) -- the
+ *            batch reduction sum_b g (.) x runs over n_slabs row slabs per sample, combined in slab order by a second,
+ *            tiny launch inside the same call (deterministic summation order; no atomics).
+ * Non-finite g propagates element-wise (no attempt to mimic the matrix route on a diverged backward pass). */
+int64_t whvi_diag_apply_bwd_slabs(int32_t dtype, int64_t S, int64_t B, int32_t log2d);
+int whvi_diag_apply_bwd_f32(void *grad_x, void *out, void *part, const void *g, const void *x, const void *s1,
+                            const void *s2, const void *u, int64_t S, int64_t B, int32_t log2d, int64_t n_slabs,
+                            int32_t flags, void *stream);
+int whvi_diag_apply_bwd_f64(void *grad_x, void *out, void *part, const void *g, const void *x, const void *s1,
+                            const void *s2, const void *u, int64_t S, int64_t B, int32_t log2d, int64_t n_slabs,
+                            int32_t flags, void *stream);
+
 /* whvi_reparam_kl_f32 with the eps draw inside the kernel: Philox4x32-10 + Box-Muller, one standard
  * normal per (matrix, sample, element), written to eps_out (J, S, D) for the backward pass / inspection.  The
  * generator state is three 64-bit words in DEVICE memory, state = {seed, launch offset, scratch (must be 0)}; the

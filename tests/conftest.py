@@ -42,3 +42,16 @@ def hip_lib():
     """The native library must be there on a GPU box -- fail loudly, never fall back."""
     from whvi_amd import _hip
     return _hip.lib()
+
+
+@pytest.fixture(params=["auto", "faithful"])
+def dataflow(request):
+    """Run a test on both evaluation routes of the square weight matrix (whvi_amd/weights.py): "auto" = the one-launch
+    diagonal application on the GPU (the shipped default), "faithful" = weight construction through the FWHT kernels + the
+    dense GEMM, the reference's dataflow op for op (src/weights.py:87-93)."""
+    from whvi_amd.weights import WHVISquarePow2Matrix
+    # (not through ``monkeypatch``: several of these tests call monkeypatch.undo() half way to drop a torch.randn replay)
+    before = WHVISquarePow2Matrix.default_exploit_diagonal
+    WHVISquarePow2Matrix.default_exploit_diagonal = "auto" if request.param == "auto" else False
+    yield request.param
+    WHVISquarePow2Matrix.default_exploit_diagonal = before

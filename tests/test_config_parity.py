@@ -133,7 +133,7 @@ def test_config4_layer_vs_reference_cpu(name, mode, monkeypatch):
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["loop", "batched"])
 @pytest.mark.parametrize("name", C4_LAYERS)
-def test_config4_layer_vs_reference_gpu(name, mode, monkeypatch, hip_lib):
+def test_config4_layer_vs_reference_gpu(name, mode, monkeypatch, hip_lib, dataflow):
     run_config4_layer(name, "cuda", monkeypatch, mode)
 
 
@@ -183,7 +183,7 @@ def test_config4_network_vs_reference_cpu(mode, monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["loop", "batched"])
-def test_config4_network_vs_reference_gpu(mode, monkeypatch, hip_lib):
+def test_config4_network_vs_reference_gpu(mode, monkeypatch, hip_lib, dataflow):
     run_config4_network("cuda", monkeypatch, mode)
 
 
@@ -279,7 +279,7 @@ def test_train_trajectory_batched_pass_cpu(monkeypatch, tmp_path):
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["loop", "batched"])
 @pytest.mark.parametrize("run", ["default", "fast"])
-def test_train_trajectory_vs_reference_gpu(run, mode, monkeypatch, tmp_path, hip_lib):
+def test_train_trajectory_vs_reference_gpu(run, mode, monkeypatch, tmp_path, hip_lib, dataflow):
     """Bars: 1e-5 relative on the first step's loss (north_star) and on all 21; parameters after 21 Adam steps
     within 2 % of the distance the reference moved them (Adam normalises gradients, so rounding-level gradient
     differences on near-zero entries turn into O(lr) step differences; the looser bound states that)."""
@@ -354,7 +354,7 @@ def test_one_launch_schedule_is_the_reference_schedule_gpu(hip_lib):
 @pytest.mark.gpu
 @pytest.mark.parametrize("packed", [False, True])
 @pytest.mark.parametrize("run", ["default", "fast"])
-def test_train_trajectory_graphed_vs_reference_gpu(run, packed, tmp_path, hip_lib):
+def test_train_trajectory_graphed_vs_reference_gpu(run, packed, tmp_path, hip_lib, dataflow):
     """The reference's training recipe on the FAST path: ``train_model(graphed=True)`` -- both phases,
     ``scheduler.step()`` after every batch (src/networks.py:80-81), the checkpoint of phase 2 -- with every step one
     hipGraph replay holding loss, backward, Adam and the schedule (learning rate and step counter in device memory).
@@ -423,7 +423,7 @@ def _bits(a):
 
 
 @pytest.mark.gpu
-def test_config2_full_size_forward_mc_vs_oracle(monkeypatch, hip_lib):
+def test_config2_full_size_forward_mc_vs_oracle(monkeypatch, hip_lib, dataflow):
     """BASELINE config 2 as timed: ``WHVILinear(512, 512)`` forward + KL, 32 MC samples, batch 4096, fp32, through
     ``forward_mc``.  Every sample's output on 48 sampled batch rows against oracle/whvi_oracle.py (pinned to the
     reference's bundles), 1e-5 relative; KL against the oracle's."""

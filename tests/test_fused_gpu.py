@@ -151,11 +151,11 @@ def test_per_sample_outer_scales_bit_exact(hip_lib):
 
 @pytest.mark.parametrize("name", ["sq8", "sq64b", "sq512", "sq4096", "st3x16", "st5x7b", "st13x128",
                                   "col1x10b", "col16x1"])
-def test_layer_forward_kl_backward_vs_reference_gpu(name, monkeypatch, hip_lib):
+def test_layer_forward_kl_backward_vs_reference_gpu(name, monkeypatch, hip_lib, dataflow):
     run_layer_bundle(name, DEV, monkeypatch, rtol=1e-5)
 
 
-def test_square_layer_matches_numpy_oracle_tightly(monkeypatch, hip_lib):
+def test_square_layer_matches_numpy_oracle_tightly(monkeypatch, hip_lib, dataflow):
     """D = 4096: the reference's host path is butterflies too, so the GPU layer, the oracle and the
     recorded reference output agree to the last bits (softplus ulp aside)."""
     b = _bundle("sq4096")
@@ -170,7 +170,7 @@ def test_square_layer_matches_numpy_oracle_tightly(monkeypatch, hip_lib):
     assert np.abs(y - want).max() <= 2e-7 * scale
 
 
-def test_network_on_gpu_equals_host_path(monkeypatch, hip_lib):
+def test_network_on_gpu_equals_host_path(monkeypatch, hip_lib, dataflow):
     """A 3 -> 64 -> 64 -> 1 network with all three layer flavours: loss, predictions and every gradient on the GPU
     (fused kernels) against the host path (the reference's op chain under plain autograd) for the same parameters and
     the same eps -- 1e-5 relative on values, 3e-5 on gradients (the host's dense-H matmul carries its own rounding)."""
@@ -209,7 +209,7 @@ def test_network_on_gpu_equals_host_path(monkeypatch, hip_lib):
     assert dev(x.to(DEV)).shape == (17, 1, 3)
 
 
-def test_batched_mc_pass_equals_loop_gpu(monkeypatch, hip_lib):
+def test_batched_mc_pass_equals_loop_gpu(monkeypatch, hip_lib, dataflow):
     loop_vs_batched(DEV, monkeypatch)
 
 
@@ -314,7 +314,7 @@ def test_tiny_layers_on_gpu(monkeypatch, hip_lib):
 
 @pytest.mark.parametrize("n_in,n_out", [(2, 5), (2, 2), (1, 1), (1, 3), (3, 1), (2, 1), (5, 7), (7, 2), (16, 4),
                                         (6, 64), (64, 64), (33, 100)])
-def test_layer_values_vs_numpy_oracle_gpu(n_in, n_out, monkeypatch, hip_lib):
+def test_layer_values_vs_numpy_oracle_gpu(n_in, n_out, monkeypatch, hip_lib, dataflow):
     """Forward values of every WHVILinear flavour on the GPU against the numpy restatement of the reference
     (oracle/whvi_oracle.py, itself pinned to the reference's recorded bundles), eps replayed; 1e-5 relative."""
     torch.manual_seed(n_in * 131 + n_out)
@@ -696,7 +696,7 @@ def test_gauss_mnll_kernel_vs_reference_formula(m, n_out, n_mc, layout, hip_lib)
 
 @pytest.mark.parametrize("n_in,n_out", [(8, 8), (64, 64), (512, 512), (3, 16), (5, 7), (13, 128), (100, 33), (4, 1024),
                                         (1, 10), (1, 128), (16, 1), (100, 1), (2, 2), (2, 5), (1, 1)])
-def test_layer_gradients_gpu_vs_host_path(n_in, n_out, monkeypatch, hip_lib):
+def test_layer_gradients_gpu_vs_host_path(n_in, n_out, monkeypatch, hip_lib, dataflow):
     """Every WHVILinear flavour (square / stacked / column / transposed column): forward output and ALL gradients
     (s1, s2, g_mu, g_rho, bias, input) on the GPU -- fused weight kernel, one-launch backward kernels -- against the
     host path, which runs the reference's op chain under plain autograd (src/weights.py:34-41,66-93), with the
@@ -890,7 +890,7 @@ def test_packed_stacked_layer_on_gpu(monkeypatch, hip_lib):
             assert float((got - want).abs().max()) <= 1e-6 * float(want.abs().max()), (use_mc, name)
 
 
-def test_network_and_likelihood_vs_reference_on_gpu(monkeypatch, hip_lib):
+def test_network_and_likelihood_vs_reference_on_gpu(monkeypatch, hip_lib, dataflow):
     """The reference's recorded WHVIRegression run (tests/golden/network_golden.npz: predictions, MNLL, KL for replayed
     eps) and its likelihood unit tests (test/likelihoods.py:8-56) with the network on the GPU: fused weight kernels,
     one-launch Gaussian MNLL reduction.  1e-5 relative."""

@@ -8,7 +8,11 @@ WHVI_WBAR_FWD_TILES, WHVI_STREAM_BIG_BLOCKS, ...) or a -D override call
     _tuning.use("nopk", "-DWHVI_NO_PK")                   # a -D variant under its own tag
 
 which builds whvi_amd/_exp/libwhvi_hip_<tag>.so with -DWHVI_TUNING_BUILD (make -C whvi_amd/csrc tuning) when it is
-missing or older than the kernel sources and points WHVI_HIP_LIB at it.  Build in the container: the GPU box has the
+missing or older than the kernel sources and makes whvi_amd._hip load it (assigns its LIB_PATH: the shipped loader reads
+no environment).  To run an unmodified script (bench.py, a probe) on such a build:
+
+    python tools/_tuning.py --run whvi_amd/_exp/libwhvi_hip_<tag>.so bench.py --no-extras ...
+  Build in the container: the GPU box has the
 compiler too, but its minutes are better spent measuring."""
 import glob
 import os
@@ -31,12 +35,28 @@ def build(tag: str = "tuning", defs: str = "") -> str:
     return out
 
 
+def load(path: str) -> str:
+    """Make whvi_amd._hip load the library at ``path`` (must run before its first native call)."""
+    import sys
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    from whvi_amd import _hip
+    if _hip._lib is not None and _hip.LIB_PATH != path:
+        raise RuntimeError("_tuning.load: whvi_amd has already loaded " + _hip.LIB_PATH)
+    _hip.LIB_PATH = os.path.abspath(path)
+    return _hip.LIB_PATH
+
+
 def use(tag: str = "tuning", defs: str = "") -> str:
-    path = build(tag, defs)
-    os.environ["WHVI_HIP_LIB"] = path
-    return path
+    return load(build(tag, defs))
 
 
 if __name__ == "__main__":
+    import runpy
     import sys
-    print(build(*(sys.argv[1:3])))
+    if len(sys.argv) >= 4 and sys.argv[1] == "--run":          # --run <lib.so> <script.py> [args...]
+        load(sys.argv[2])
+        sys.argv = sys.argv[3:]
+        runpy.run_path(sys.argv[0], run_name="__main__")
+    else:
+        print(build(*(sys.argv[1:3])))

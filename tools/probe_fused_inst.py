@@ -1,6 +1,6 @@
 """tools/probe_fused_inst.py -- TB/s and kernel symbol of the fused S.H.diag(g).H.S launch per instantiation family:
 f32 / f64, shared vs per-sample outer scale vectors (WHVI_FUSED_{A,C}_PER_SAMPLE), D = 512 .. 4096, 4 GiB in place,
-plus the stacked-layer weight construction (J = 256 sub-matrices of D = 4, whvi_wbar_fwd).  Set WHVI_HIP_LIB to A/B
+plus the stacked-layer weight construction (J = 256 sub-matrices of D = 4, whvi_wbar_fwd).  Run under `python tools/_tuning.py --run <lib.so> tools/probe_fused_inst.py ...` to A/B
 another build of the library."""
 import os
 import sys

@@ -1,5 +1,5 @@
 """tools/probe_rows_forms.py [GiB] -- the streaming launch of the plain transform per storage type and D (in place, HIP events):
-TB/s and kernel symbol.  Run it under two builds (WHVI_HIP_LIB) for an A/B of a launch / code form, e.g. the tile loop
+TB/s and kernel symbol.  Run it under two builds (python tools/_tuning.py --run <lib.so> <script>) for an A/B of a launch / code form, e.g. the tile loop
 of the store-barrier kernels run once (`make tuning TAG=sp DEFS=-DWHVI_ALIGN_SINGLE_PASS=1`) against the generic loop."""
 import os
 import sys

@@ -16,8 +16,9 @@ import threading
 import torch  # noqa: F401  (must be loaded before the HIP library, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# WHVI_HIP_LIB: path of an alternative build of the SAME library (tuning A/Bs, tools/); there is no other implementation
-LIB_PATH = os.environ.get("WHVI_HIP_LIB") or os.path.join(_HERE, "libwhvi_hip.so")
+# The shipped loader reads NO environment: it loads the library built next to this file, or nothing.  (Measurement builds of
+# the same library are loaded by the probes under tools/ by assigning LIB_PATH before the first call: tools/_tuning.py.)
+LIB_PATH = os.path.join(_HERE, "libwhvi_hip.so")
 
 AXIS_ROW, AXIS_COL = 0, 1
 F32, F64, F16, I32, BF16 = 0, 1, 2, 3, 4
@@ -89,6 +90,14 @@ def _declare_f3(lib):
         fn = getattr(lib, "whvi_wbar_fwd_mean_" + sfx)
         fn.restype = ctypes.c_int
         fn.argtypes = [vp, vp, vp, vp, i64, i64, i64, ctypes.c_int32, vp]
+        fn = getattr(lib, "whvi_diag_apply_" + sfx)
+        fn.restype = ctypes.c_int
+        fn.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, ctypes.c_int32, ctypes.c_int32, vp]
+        fn = getattr(lib, "whvi_diag_apply_bwd_" + sfx)
+        fn.restype = ctypes.c_int
+        fn.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, ctypes.c_int32, i64, ctypes.c_int32, vp]
+    lib.whvi_diag_apply_bwd_slabs.restype = ctypes.c_int64
+    lib.whvi_diag_apply_bwd_slabs.argtypes = [ctypes.c_int32, i64, i64, ctypes.c_int32]
 
 
 def lib():
@@ -426,6 +435,88 @@ def wbar_bwd(grad_w: torch.Tensor, s1: torch.Tensor, u: torch.Tensor, s2: torch.
                 _stream(grad_w))
     _check(rc, "whvi_wbar_bwd")
     return out
+
+
+DIAG_X_SHARED, DIAG_MEAN_PLUS = 1, 2
+
+
+def diag_apply_supported(dtype: torch.dtype, d: int) -> bool:
+    """Row lengths ``whvi_diag_apply_*`` covers: one 16-byte chunk up to one 64-register wavefront tile."""
+    if dtype == torch.float32:
+        return 4 <= d <= 4096 and (d & (d - 1)) == 0
+    return dtype == torch.float64 and 2 <= d <= 2048 and (d & (d - 1)) == 0
+
+
+def _diag_operands(x, s1, s2, u, n_samples, mean_plus, what):
+    if x.device.type != "cuda" or x.dtype not in (torch.float32, torch.float64):
+        raise RuntimeError(f"{what}: float32 / float64 CUDA tensors only")
+    D = x.shape[-1]
+    if not diag_apply_supported(x.dtype, D):
+        raise RuntimeError(f"{what}: D = {D} is outside the supported range for {x.dtype}")
+    S = int(n_samples)
+    if x.dim() == 3 and x.shape[0] == S:
+        shared, B = False, x.shape[1]
+    elif x.dim() == 2:
+        shared, B = True, x.shape[0]
+    else:
+        raise RuntimeError(f"{what}: x must be (n_samples, batch, D) or (batch, D)")
+    U = S + (1 if mean_plus else 0)
+    if tuple(u.shape) != (U, D) or tuple(s1.shape) != (D,) or tuple(s2.shape) != (D,):
+        raise RuntimeError(f"{what}: operand shapes do not match x (u must be ({U}, {D}))")
+    if not (u.dtype == s1.dtype == s2.dtype == x.dtype):
+        raise RuntimeError(f"{what}: operand dtypes do not match x")
+    flags = (DIAG_X_SHARED if shared else 0) | (DIAG_MEAN_PLUS if mean_plus else 0)
+    return S, B, D, shared, flags
+
+
+def diag_apply(x: torch.Tensor, s1: torch.Tensor, s2: torch.Tensor, u: torch.Tensor, bias: torch.Tensor = None, *,
+               n_samples: int, mean_plus: bool = True, out: torch.Tensor = None) -> torch.Tensor:
+    """One launch: ``out[k] = x[(k)] * (wd(u[0]) + wd(u[1 + k])) + bias`` -- ``h @ (w_bar(g_mu) + w_bar(g_sigma eps_k)).T``
+    of src/weights.py:87-93 for all MC samples without the matrices; see whvi_diag_apply_f32 in include/whvi_hip.h.
+    ``x``: (S, B, D) or a shared (B, D); ``u``: (1 + S, D), or (S, D) with ``mean_plus=False``; returns (S, B, D)."""
+    S, B, D, shared, flags = _diag_operands(x, s1, s2, u, n_samples, mean_plus, "diag_apply")
+    x, s1, s2, u = _aligned(x), _aligned(s1), _aligned(s2), _aligned(u)
+    if bias is not None:
+        if bias.numel() != D or bias.dtype != x.dtype:
+            raise RuntimeError("diag_apply: bias must hold D elements of x's dtype")
+        bias = _aligned(bias.reshape(-1))
+    if out is None:
+        out = torch.empty((S, B, D), dtype=x.dtype, device=x.device)
+    elif not out.is_contiguous() or tuple(out.shape) != (S, B, D) or out.dtype != x.dtype or out.data_ptr() % 16:
+        raise RuntimeError("diag_apply: bad out tensor")
+    fn = getattr(lib(), "whvi_diag_apply_" + _DTYPE_SUFFIX[x.dtype])
+    with _OnDevice(x.device):
+        rc = fn(out.data_ptr(), x.data_ptr(), s1.data_ptr(), s2.data_ptr(), u.data_ptr(),
+                None if bias is None else bias.data_ptr(), S, B, D.bit_length() - 1, flags, _stream(x))
+    _check(rc, "whvi_diag_apply")
+    return out
+
+
+def diag_apply_bwd(grad_out: torch.Tensor, x: torch.Tensor, s1: torch.Tensor, s2: torch.Tensor, u: torch.Tensor, *,
+                   n_samples: int, mean_plus: bool = True, need_grad_x: bool = True):
+    """Backward of ``diag_apply`` in one call: ``(grad_x (S, B, D) or None, out (4, U, D))`` with the rows of ``out`` as
+    whvi_diag_apply_bwd_f32 documents them (slot 0 dL/du, 1 / 2 the per-sample shares of dL/ds1 / dL/ds2, 3 of dL/dbias;
+    with ``mean_plus`` row 0 is left for the caller's sum over rows 1 ..)."""
+    S, B, D, shared, flags = _diag_operands(x, s1, s2, u, n_samples, mean_plus, "diag_apply_bwd")
+    if tuple(grad_out.shape) != (S, B, D) or grad_out.dtype != x.dtype:
+        raise RuntimeError("diag_apply_bwd: grad_out must be (n_samples, batch, D) of x's dtype")
+    grad_out, x, s1, s2, u = _aligned(grad_out), _aligned(x), _aligned(s1), _aligned(s2), _aligned(u)
+    L = lib()
+    log2d = D.bit_length() - 1
+    U = u.shape[0]
+    out = torch.empty((4, U, D), dtype=x.dtype, device=x.device)
+    grad_x = torch.empty((S, B, D), dtype=x.dtype, device=x.device) if need_grad_x else None
+    if S == 0 or B == 0:
+        out.zero_()
+        return grad_x, out
+    n_slabs = int(L.whvi_diag_apply_bwd_slabs(_DTYPE_CODE[x.dtype], S, B, log2d))
+    part = torch.empty((S, n_slabs, 2, D), dtype=x.dtype, device=x.device)
+    fn = getattr(L, "whvi_diag_apply_bwd_" + _DTYPE_SUFFIX[x.dtype])
+    with _OnDevice(x.device):
+        rc = fn(None if grad_x is None else grad_x.data_ptr(), out.data_ptr(), part.data_ptr(), grad_out.data_ptr(),
+                x.data_ptr(), s1.data_ptr(), s2.data_ptr(), u.data_ptr(), S, B, log2d, n_slabs, flags, _stream(x))
+    _check(rc, "whvi_diag_apply_bwd")
+    return grad_x, out
 
 
 def reparam_kl_bwd(grad_u, grad_kl, g_mu, g_rho, eps, sigma, lambda_: float):

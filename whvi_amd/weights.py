@@ -30,7 +30,7 @@ from whvi_amd.fwht.python import FWHTFunction as fwht_python
 from whvi_amd.fwht.python import WHT_matmul as wht_matmul
 
 __all__ = ["WHVISquarePow2Matrix", "WHVIStackedMatrix", "WHVIColumnMatrix", "WBarFunction", "ReparamKLFunction",
-           "ReparamKLPhiloxFunction"]
+           "ReparamKLPhiloxFunction", "DiagApplyFunction"]
 
 
 class WBarFunction(torch.autograd.Function):
@@ -114,6 +114,74 @@ class WBarFunction(torch.autograd.Function):
                 pad = (0, D - R)
                 grad_s1, grad_u, grad_s2 = (F.pad(grad_s1_r, pad), F.pad(grad_u_r, pad), F.pad(grad_s2_r, pad))
         return grad_s1, grad_u, grad_s2, None, None
+
+
+class DiagApplyFunction(torch.autograd.Function):
+    """``out[k] = x[(k)] @ (w_bar(u[0]) + w_bar(u[1 + k])).T (+ bias)`` for every MC sample k in ONE HIP launch that never
+    builds the matrices (``whvi_diag_apply``, whvi_amd/csrc/diag_apply.hpp).
+
+    As written in the reference ``w_bar(u)`` is exactly ``D * diag(s1 * u * s2)`` (SURVEY.md finding 1), so the dense
+    product of src/weights.py:93 adds exact zeros to one product per output.  The kernel computes that product with the
+    roundings of the as-written chain in the same order -- ``u * s2``, ``D * .`` (exact), ``s1 * .``, mean + sample,
+    ``h * w``, ``+ bias`` -- hence the same values as weight construction + GEMM for every input, non-finite ones
+    included (a row of ``x`` with an inf / NaN turns its other outputs into NaN like the dot products with W's exact
+    zeros do); only the sign of a zero result may differ (the GEMM's sum of signed zeros).
+
+    ``x``: (S, B, D) or a shared (B, D); ``u``: (1 + S, D) with ``mean_plus`` (the buffer the reparameterisation kernel
+    writes) else (S, D); ``s1, s2``: (D,); ``bias``: D elements or None.  Backward: one call (``whvi_diag_apply_bwd``:
+    grad_x = g * w and the batch reduction sum_b g * x in the same pass, a tiny finishing launch) plus one reduction
+    over the samples; with ``create_graph`` the same expression as differentiable torch ops."""
+
+    @staticmethod
+    def forward(ctx, x, s1, s2, u, bias, n_samples, mean_plus):
+        from whvi_amd import _hip
+        ctx.save_for_backward(x, s1, s2, u)
+        ctx.n_samples, ctx.mean_plus = int(n_samples), bool(mean_plus)
+        ctx.bias_shape = None if bias is None else tuple(bias.shape)
+        return _hip.diag_apply(x, s1, s2, u, bias, n_samples=n_samples, mean_plus=mean_plus)
+
+    @staticmethod
+    def _reference_ops(x, s1, s2, u, bias, mean_plus):
+        """The same expression as differentiable torch ops (finite operands): double backward, shapes the kernel lacks."""
+        D = float(s1.shape[0])
+        w = s1 * (D * (u * s2))                                   # (U, D): diag(w_bar(u_r)), the reference's roundings
+        if mean_plus:
+            w = _mean_plus_rest(w, 0)                             # (S, D)
+        out = (x if x.dim() == 3 else x.unsqueeze(0)) * w.unsqueeze(1)
+        return out + bias.reshape(-1) if bias is not None else out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from whvi_amd import _hip
+        x, s1, s2, u = ctx.saved_tensors
+        S, mean_plus = ctx.n_samples, ctx.mean_plus
+        need = ctx.needs_input_grad
+        if torch.is_grad_enabled():
+            # create_graph=True: the first-order gradients as differentiable functions of (grad_out, x, s1, s2, u)
+            D = float(s1.shape[0])
+            w = s1 * (D * (u * s2))
+            w_k = _mean_plus_rest(w, 0) if mean_plus else w
+            gx = grad_out * w_k.unsqueeze(1)
+            if x.dim() == 2:
+                gx = gx.sum(dim=0)
+            gw = (grad_out * (x if x.dim() == 3 else x.unsqueeze(0))).sum(dim=1)                    # (S, D)
+            gw_u = torch.cat((gw.sum(dim=0, keepdim=True), gw), dim=0) if mean_plus else gw      # d w_k / d w_r
+            grad_u = gw_u * (s1 * D * s2)
+            grad_s1 = (gw_u * (D * (u * s2))).sum(dim=0)
+            grad_s2 = (gw_u * (s1 * D * u)).sum(dim=0)
+            grad_bias = grad_out.sum(dim=(0, 1)).reshape(ctx.bias_shape) if ctx.bias_shape is not None else None
+            return gx, grad_s1, grad_s2, grad_u, grad_bias, None, None
+        gx, out = _hip.diag_apply_bwd(grad_out, x, s1, s2, u, n_samples=S, mean_plus=mean_plus, need_grad_x=need[0])
+        if mean_plus:
+            # row 0 <- sum of the sample rows: dL/du_mean and the totals of s1 / s2 / bias, one reduction for all four
+            torch.sum(out[:, 1:], dim=1, out=out[:, 0])
+            grad_u, tot = out[0], out[1:, 0]
+        else:
+            grad_u, tot = out[0], (out[1:, 0] if S == 1 else out[1:].sum(dim=1))
+        if gx is not None and x.dim() == 2:
+            gx = gx.sum(dim=0)
+        grad_bias = tot[2].reshape(ctx.bias_shape) if ctx.bias_shape is not None else None
+        return gx, tot[0], tot[1], grad_u, grad_bias, None, None
 
 
 class ReparamKLFunction(torch.autograd.Function):
@@ -244,6 +312,7 @@ def _draw_and_reparam(module, g_mu, g_rho, n_samples, lambda_):
 
 class WHVISquarePow2Matrix(nn.Module):
     inkernel_rng = False      # opt-in: draw eps inside the reparameterisation kernel (batched MC passes on the GPU)
+    default_exploit_diagonal = "auto"      # see __init__; tests flip it to run every golden check on both routes
 
     def __init__(self, D, lambda_=1e-5, bias=False):
         """Square (D, D) WHVI matrix, D a power of two (src/weights.py:14-32).
@@ -256,12 +325,16 @@ class WHVISquarePow2Matrix(nn.Module):
         self.D = D
         self.lambda_ = lambda_
         self.padding = 0  # interface parity with the stacked matrix
-        # Opt-in shortcut (default off = the reference's dataflow, FWHTs + dense GEMM).  As written in the
-        # reference, w_bar(u) is EXACTLY D * diag(s1 * u * s2) (SURVEY.md finding 1; with butterflies the
-        # off-diagonals are exact zeros), so h @ W.T equals the elementwise h * diag(W) bit for bit for
-        # finite h.  Setting this flag computes that diagonal directly with the same roundings and skips
-        # both the D x D weight construction and the GEMM.
-        self.exploit_diagonal = False
+        # How `h @ W.T` is evaluated.  As written in the reference, w_bar(u) is EXACTLY D * diag(s1 * u * s2)
+        # (SURVEY.md finding 1; with butterflies the off-diagonals are exact zeros), so the dense product equals the
+        # elementwise h * diag(W) with the same roundings.
+        #   "auto" (default): GPU tensors take ONE launch per layer call for all MC samples that applies the diagonal
+        #       (DiagApplyFunction -- same values as the matrix route, non-finite inputs included, no D x D matrices, no
+        #       GEMM); host tensors keep the reference's dataflow;
+        #   False (= ``faithful_dataflow = True``): the as-written route everywhere -- weight construction through the
+        #       FWHT kernels + dense GEMM;
+        #   True: the diagonal everywhere (torch ops on the host).
+        self.exploit_diagonal = None      # None = the class default below
         self.wht_slow = wht_matmul()  # dense-H transform for small host matrices; H built lazily
 
         # creation order = the reference's RNG consumption order (bias, s1, s2, g_mu, g_rho)
@@ -320,22 +393,62 @@ class WHVISquarePow2Matrix(nn.Module):
         one-hot row (exact: D * .), s1 * ."""
         return self.s1 * (float(self.D) * (u * self.s2))
 
-    def sample_lrt(self, h):
+    @property
+    def faithful_dataflow(self):
+        """True = the as-written route (weight construction + dense GEMM) on every device."""
+        return self._diag_mode() is False
+
+    @faithful_dataflow.setter
+    def faithful_dataflow(self, value):
+        self.exploit_diagonal = False if value else "auto"
+
+    def _diag_mode(self):
+        mode = self.exploit_diagonal
+        return type(self).default_exploit_diagonal if mode is None else mode
+
+    def _diag_route(self, x):
+        """"kernel" (one HIP launch), "ops" (the diagonal as torch ops) or None (the as-written matrix route)."""
+        mode = self._diag_mode()
+        if mode is False:
+            return None
+        if x.device.type == "cuda" and x.dtype == self.g_mu.dtype:
+            from whvi_amd import _hip
+            if _hip.diag_apply_supported(x.dtype, self.D):
+                return "kernel"
+        return "ops" if mode is True else None
+
+    def _diag_kernel(self, x, u, bias, n_samples, mean_plus):
+        """x: (..., D) shared by all samples when ``n_samples`` is None (one sample), else (S, B, D) / (B, D)."""
+        if n_samples is None:
+            out = DiagApplyFunction.apply(x.reshape(1, -1, self.D), self.s1, self.s2, u, bias, 1, mean_plus)
+            return out.view(x.shape)
+        return DiagApplyFunction.apply(x, self.s1, self.s2, u, bias, n_samples, mean_plus)
+
+    def sample_lrt(self, h, _bias=None):
         """``h @ (w_bar(g_mu) + w_bar(g_sigma * eps)).T`` with one eps per call
-        (src/weights.py:87-93).  On the GPU both ``w_bar`` matrices come from a single launch."""
+        (src/weights.py:87-93).  On the GPU: one launch that applies the diagonal both matrices have, or (faithful
+        dataflow) both ``w_bar`` matrices from a single launch and the dense product."""
         epsilon = torch.randn(self.D, device=self.g_mu.device)
-        if self.exploit_diagonal:
-            return h * (self._w_bar_diagonal(self.g_mu) + self._w_bar_diagonal(self.g_sigma * epsilon))
-        if self.g_mu.device.type == "cuda":
+        route = self._diag_route(h)
+        if route == "kernel":
+            return self._diag_kernel(h, torch.stack((self.g_mu, self.g_sigma * epsilon)), _bias, None, True)
+        if route == "ops":
+            out = h * (self._w_bar_diagonal(self.g_mu) + self._w_bar_diagonal(self.g_sigma * epsilon))
+        elif self.g_mu.device.type == "cuda":
             W = self._w_bar_stack(torch.stack((self.g_mu, self.g_sigma * epsilon)), mean_plus=True)   # (1, D, D)
-            return h @ W.squeeze(0).T
-        return h @ (self.w_bar(self.g_mu) + self.w_bar(self.g_sigma * epsilon)).T
+            out = h @ W.squeeze(0).T
+        else:
+            out = h @ (self.w_bar(self.g_mu) + self.w_bar(self.g_sigma * epsilon)).T
+        return out + _bias if _bias is not None else out
 
     def forward(self, x, use_lrt=True):
         """(src/weights.py:95-108) ``x``: (batch, D)."""
         if use_lrt:
-            out = self.sample_lrt(x)
-            return out + self.bias if self.bias is not None else out
+            return self.sample_lrt(x, self.bias)
+        if self._diag_route(x) == "kernel":
+            epsilon = torch.randn(self.D, device=self.g_mu.device)          # sample()'s draw
+            g_tilde = self.g_mu + self.g_sigma * epsilon
+            return self._diag_kernel(x, g_tilde.unsqueeze(0), self.bias, None, False)
         return F.linear(x, self.sample(), self.bias)
 
     def forward_mc(self, x, n_samples):
@@ -344,15 +457,17 @@ class WHVISquarePow2Matrix(nn.Module):
         what ``forward`` computes with the k-th row of one ``randn(n_samples, D)`` draw: one fused
         launch builds every sample's weight matrix, one batched GEMM applies them."""
         self._mc_kl = None
-        if self.exploit_diagonal:
-            eps = torch.randn(n_samples, self.D, device=self.g_mu.device)
-            w = self._w_bar_diagonal(self.g_mu) + self._w_bar_diagonal(self.g_sigma * eps)   # (S, D)
-            out = (x if x.dim() == 3 else x.unsqueeze(0)) * w.unsqueeze(1)
-            return out + self.bias if self.bias is not None else out
         # one randn(S, D) draw (or the in-kernel generator), softplus, g_sigma * eps and the KL terms
         u, kl = _draw_and_reparam(self, self.g_mu.unsqueeze(0), self.g_rho.unsqueeze(0), n_samples, self.lambda_)
         u = u.squeeze(0)                                                          # (1 + S, D)
         self._mc_kl = None if kl is None else kl.squeeze(0)   # KL of this pass, for WHVINetwork.loss
+        route = self._diag_route(x)
+        if route == "kernel":
+            return self._diag_kernel(x, u, self.bias, n_samples, True)           # (S, batch, D), bias included
+        if route == "ops":
+            w = _mean_plus_rest(self._w_bar_diagonal(u), 0)                       # (S, D)
+            out = (x if x.dim() == 3 else x.unsqueeze(0)) * w.unsqueeze(1)
+            return out + self.bias if self.bias is not None else out
         if u.device.type == "cuda":
             W = self._w_bar_stack(u, mean_plus=True)                             # (S, D, D), the sum in-kernel
         else:
