@@ -265,6 +265,12 @@ int whvi_wbar_bwd_f64(void *grad_u, void *part_s1, void *part_s2, const void *gr
  *   log2d in [2, 12] (f32) / [1, 11] (f64). */
 #define WHVI_DIAG_X_SHARED  1
 #define WHVI_DIAG_MEAN_PLUS 2
+/* tuning / cross-check (same values either way): force the streaming (non-temporal) or the cached launch instead of the
+ * choice by size; keep the plain block order on a shared input */
+#define WHVI_DIAG_TUNE_NT          16
+#define WHVI_DIAG_TUNE_CACHED      32
+#define WHVI_DIAG_TUNE_PLAIN_ORDER 64
+#define WHVI_DIAG_TUNE_MASK        (16 | 32 | 64)
 int whvi_diag_apply_f32(void *out, const void *x, const void *s1, const void *s2, const void *u, const void *bias,
                         int64_t S, int64_t B, int32_t log2d, int32_t flags, void *stream);
 int whvi_diag_apply_f64(void *out, const void *x, const void *s1, const void *s2, const void *u, const void *bias,

@@ -183,7 +183,10 @@ def test_backward_vs_the_matrix_route_autograd(dtype, D, S, B, shared, hip_lib):
     gout = torch.randn(S, B, D, device=DEV, dtype=dtype, generator=g)
     leaves = [t.clone().requires_grad_(True) for t in (x, s1, s2, u, bias)]
     got = torch.autograd.grad(DiagApplyFunction.apply(*leaves, S, True), leaves, gout)
-    assert _hip.last_kernel().startswith("whvi::diag_apply_bwd_kernel<")
+    # (the launch note is per thread and autograd ran the backward on its own: name the kernel through a direct call)
+    direct = _hip.diag_apply_bwd(gout, x, s1, s2, u, n_samples=S)
+    assert _hip.last_kernel().startswith("whvi::diag_apply_bwd_kernel<") and _hip.last_kernel().endswith(", true>")
+    assert torch.equal(direct[0] if not shared else direct[0].sum(dim=0), got[0])
     ref_leaves = [t.clone().requires_grad_(True) for t in (x, s1, s2, u, bias)]
     want = torch.autograd.grad(matrix_route(*ref_leaves), ref_leaves, gout)
     tol = 1e-5 if dtype == torch.float32 else 1e-12
@@ -199,7 +202,7 @@ def test_backward_vs_the_matrix_route_autograd(dtype, D, S, B, shared, hip_lib):
     # no gradient wanted for the input: the kernel skips writing it
     l2 = [t.clone().requires_grad_(i > 0) for i, t in enumerate((x, s1, s2, u, bias))]
     again = torch.autograd.grad(DiagApplyFunction.apply(*l2, S, True), l2[1:], gout)
-    assert ", false>" in _hip.last_kernel()
+    assert _hip.diag_apply_bwd(gout, x, s1, s2, u, n_samples=S, need_grad_x=False)[0] is None and _hip.last_kernel().endswith(", false>")
     for a, b in zip(again, got[1:]):
         assert torch.equal(a, b)
 

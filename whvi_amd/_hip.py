@@ -438,6 +438,7 @@ def wbar_bwd(grad_w: torch.Tensor, s1: torch.Tensor, u: torch.Tensor, s2: torch.
 
 
 DIAG_X_SHARED, DIAG_MEAN_PLUS = 1, 2
+DIAG_TUNE_NT, DIAG_TUNE_CACHED, DIAG_TUNE_PLAIN_ORDER = 16, 32, 64      # tuning / cross-check flags (include/whvi_hip.h)
 
 
 def diag_apply_supported(dtype: torch.dtype, d: int) -> bool:
@@ -470,7 +471,7 @@ def _diag_operands(x, s1, s2, u, n_samples, mean_plus, what):
 
 
 def diag_apply(x: torch.Tensor, s1: torch.Tensor, s2: torch.Tensor, u: torch.Tensor, bias: torch.Tensor = None, *,
-               n_samples: int, mean_plus: bool = True, out: torch.Tensor = None) -> torch.Tensor:
+               n_samples: int, mean_plus: bool = True, out: torch.Tensor = None, tune: int = 0) -> torch.Tensor:
     """One launch: ``out[k] = x[(k)] * (wd(u[0]) + wd(u[1 + k])) + bias`` -- ``h @ (w_bar(g_mu) + w_bar(g_sigma eps_k)).T``
     of src/weights.py:87-93 for all MC samples without the matrices; see whvi_diag_apply_f32 in include/whvi_hip.h.
     ``x``: (S, B, D) or a shared (B, D); ``u``: (1 + S, D), or (S, D) with ``mean_plus=False``; returns (S, B, D)."""
@@ -487,13 +488,13 @@ def diag_apply(x: torch.Tensor, s1: torch.Tensor, s2: torch.Tensor, u: torch.Ten
     fn = getattr(lib(), "whvi_diag_apply_" + _DTYPE_SUFFIX[x.dtype])
     with _OnDevice(x.device):
         rc = fn(out.data_ptr(), x.data_ptr(), s1.data_ptr(), s2.data_ptr(), u.data_ptr(),
-                None if bias is None else bias.data_ptr(), S, B, D.bit_length() - 1, flags, _stream(x))
+                None if bias is None else bias.data_ptr(), S, B, D.bit_length() - 1, flags | int(tune), _stream(x))
     _check(rc, "whvi_diag_apply")
     return out
 
 
 def diag_apply_bwd(grad_out: torch.Tensor, x: torch.Tensor, s1: torch.Tensor, s2: torch.Tensor, u: torch.Tensor, *,
-                   n_samples: int, mean_plus: bool = True, need_grad_x: bool = True):
+                   n_samples: int, mean_plus: bool = True, need_grad_x: bool = True, tune: int = 0):
     """Backward of ``diag_apply`` in one call: ``(grad_x (S, B, D) or None, out (4, U, D))`` with the rows of ``out`` as
     whvi_diag_apply_bwd_f32 documents them (slot 0 dL/du, 1 / 2 the per-sample shares of dL/ds1 / dL/ds2, 3 of dL/dbias;
     with ``mean_plus`` row 0 is left for the caller's sum over rows 1 ..)."""
@@ -514,7 +515,7 @@ def diag_apply_bwd(grad_out: torch.Tensor, x: torch.Tensor, s1: torch.Tensor, s2
     fn = getattr(L, "whvi_diag_apply_bwd_" + _DTYPE_SUFFIX[x.dtype])
     with _OnDevice(x.device):
         rc = fn(None if grad_x is None else grad_x.data_ptr(), out.data_ptr(), part.data_ptr(), grad_out.data_ptr(),
-                x.data_ptr(), s1.data_ptr(), s2.data_ptr(), u.data_ptr(), S, B, log2d, n_slabs, flags, _stream(x))
+                x.data_ptr(), s1.data_ptr(), s2.data_ptr(), u.data_ptr(), S, B, log2d, n_slabs, flags | int(tune), _stream(x))
     _check(rc, "whvi_diag_apply_bwd")
     return grad_x, out
 

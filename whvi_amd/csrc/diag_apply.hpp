@@ -64,7 +64,7 @@ template <typename T, int LOG2D, int K, bool NT, bool XSHARED>
 __global__ void __launch_bounds__(256)
 diag_apply_kernel(u32x4 *__restrict__ dst, const u32x4 *x, const T *__restrict__ s1, const T *__restrict__ s2,
                   const T *__restrict__ u, const T *__restrict__ bias, int64_t n_chunks, int64_t n_tiles, uint32_t n_rows,
-                  FastDiv by_batch, uint32_t mean_plus)
+                  FastDiv by_batch, uint32_t mean_plus, uint32_t sample_fastest)
 {
     using E = Elem<T>;
     using A = typename E::acc;
@@ -82,6 +82,16 @@ diag_apply_kernel(u32x4 *__restrict__ dst, const u32x4 *x, const T *__restrict__
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int64_t blk = blockIdx.x;
+    if (XSHARED && sample_fastest != 0u) {
+        // shared input (host: whole blocks per sample, blocks per sample a multiple of 8 = sample_fastest * 8): blocks are dealt
+        // round-robin over the 8 XCDs; XCD c takes row groups c, c + 8, ... of the input and runs each of them for ALL samples
+        // back to back, so an input tile is fetched into that XCD's L2 once and hit S - 1 times.  (Sample-major order re-reads
+        // the whole input per sample through the fabric -- as many bytes in as out: 3.4 TB/s written at D = 1024, 16 x 8192 rows)
+        const uint32_t b = blockIdx.x, xcd = b & 7u, i = b >> 3;
+        const uint32_t n_samples = n_rows / by_batch.d;
+        const uint32_t q = i / n_samples, smp = i - q * n_samples;
+        blk = (int64_t)smp * (sample_fastest * 8u) + (q * 8u + xcd);
+    } else
     if (NT && (gridDim.x & 7) == 0) blk = (blk & 7) * (int64_t)(gridDim.x >> 3) + (blk >> 3);   // XCD-contiguous
     const int64_t t = blk * 4 + wave;
     const bool active = t < n_tiles;
@@ -395,7 +405,8 @@ inline int diag_apply_dispatch(void *dst, const void *x, const void *s1, const v
     constexpr int LV = ilog2(Elem<T>::VEC);
     g_err[0] = 0;
     if (S < 0 || B < 0) return fail(WHVI_ERR_ARG, "whvi_diag_apply: negative size%s", "");
-    if (flags & ~(WHVI_DIAG_X_SHARED | WHVI_DIAG_MEAN_PLUS)) return fail(WHVI_ERR_ARG, "whvi_diag_apply: unknown flags%s 0x%llx", "", flags);
+    if (flags & ~(WHVI_DIAG_X_SHARED | WHVI_DIAG_MEAN_PLUS | WHVI_DIAG_TUNE_MASK))
+        return fail(WHVI_ERR_ARG, "whvi_diag_apply: unknown flags%s 0x%llx", "", flags);
     if (log2d < LV || log2d > diag_max_log2d<T>())
         return fail(WHVI_ERR_SIZE, "whvi_diag_apply: log2(D)%s = %lld is outside the supported range [%lld, ...]", "", log2d, LV);
     const int64_t rows = S * B;
@@ -418,15 +429,21 @@ inline int diag_apply_dispatch(void *dst, const void *x, const void *s1, const v
     do {                                                                                                        \
         constexpr int K_ = pick_k<T, L>();                                                                      \
         const int64_t n_chunks = (rows << L) / Elem<T>::VEC, n_tiles = (n_chunks + 64 * K_ - 1) / (64 * K_);    \
+        /* shared input: sample index fastest within an XCD when every sample is a whole number of 8-block groups */ \
+        const int64_t blk_chunks = (int64_t)4 * 64 * K_, per_sample = (B << L) / Elem<T>::VEC;                  \
+        /* (streaming launches only: at cache-resident sizes -- config 2's 256 MiB -- the plain order is faster, 54 vs 64 us) */ \
+        const uint32_t fastest = (SH && NT && S > 1 && !(flags & WHVI_DIAG_TUNE_PLAIN_ORDER) && per_sample % (8 * blk_chunks) == 0) \
+                                     ? (uint32_t)(per_sample / (8 * blk_chunks)) : 0u;                          \
         note_launch<T>("diag_apply_kernel", L, K_, (bool)NT, (bool)SH);                                         \
         hipLaunchKernelGGL((diag_apply_kernel<T, L, K_, NT, SH>), dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, st, \
                            (u32x4 *)dst, (const u32x4 *)x, (const T *)s1, (const T *)s2, (const T *)u, (const T *)bias, \
-                           n_chunks, n_tiles, (uint32_t)rows, db, mean_plus);                                   \
+                           n_chunks, n_tiles, (uint32_t)rows, db, mean_plus, fastest);                          \
     } while (0)
 #define WHVI_CASE(L)                                                                                            \
     case L:                                                                                                     \
         if constexpr (L >= LV && L <= diag_max_log2d<T>()) {                                                    \
-            const bool nt = stream_sized((rows << L) * (int64_t)sizeof(T), dst, shared ? nullptr : x);          \
+            const bool nt = (flags & WHVI_DIAG_TUNE_NT) ? true : (flags & WHVI_DIAG_TUNE_CACHED) ? false           \
+                            : stream_sized((rows << L) * (int64_t)sizeof(T), dst, shared ? nullptr : x);        \
             if (shared) { if (nt) WHVI_DIAG(L, true, true); else WHVI_DIAG(L, false, true); }                   \
             else { if (nt) WHVI_DIAG(L, true, false); else WHVI_DIAG(L, false, false); }                        \
         }                                                                                                       \
@@ -449,7 +466,8 @@ inline int diag_apply_bwd_dispatch(void *grad_x, void *out, void *part, const vo
     constexpr int LV = ilog2(Elem<T>::VEC);
     g_err[0] = 0;
     if (S < 0 || B < 0) return fail(WHVI_ERR_ARG, "whvi_diag_apply_bwd: negative size%s", "");
-    if (flags & ~(WHVI_DIAG_X_SHARED | WHVI_DIAG_MEAN_PLUS)) return fail(WHVI_ERR_ARG, "whvi_diag_apply_bwd: unknown flags%s 0x%llx", "", flags);
+    if (flags & ~(WHVI_DIAG_X_SHARED | WHVI_DIAG_MEAN_PLUS | WHVI_DIAG_TUNE_MASK))
+        return fail(WHVI_ERR_ARG, "whvi_diag_apply_bwd: unknown flags%s 0x%llx", "", flags);
     if (log2d < LV || log2d > diag_max_log2d<T>())
         return fail(WHVI_ERR_SIZE, "whvi_diag_apply_bwd: log2(D)%s = %lld is outside the supported range [%lld, ...]", "", log2d, LV);
     if (S == 0) return WHVI_OK;
@@ -476,7 +494,8 @@ inline int diag_apply_bwd_dispatch(void *grad_x, void *out, void *part, const vo
 #define WHVI_CASE(L)                                                                                            \
     case L:                                                                                                     \
         if constexpr (L >= LV && L <= diag_max_log2d<T>()) {                                                    \
-            const bool nt = ((S * B) << L) * (int64_t)sizeof(T) * (grad_x ? 3 : 2) > NT_MIN_BYTES;              \
+            const bool nt = (flags & WHVI_DIAG_TUNE_NT) ? true : (flags & WHVI_DIAG_TUNE_CACHED) ? false           \
+                            : ((S * B) << L) * (int64_t)sizeof(T) * (grad_x ? 3 : 2) > NT_MIN_BYTES;            \
             if (grad_x) {                                                                                       \
                 if (shared) { if (nt) WHVI_DBWD(L, true, true, true); else WHVI_DBWD(L, false, true, true); }   \
                 else { if (nt) WHVI_DBWD(L, true, false, true); else WHVI_DBWD(L, false, false, true); }        \
