@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the WHVI hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N = 1)
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+    python bench.py --gpus N --steps K --warmup W          (any N: for N > 1 without a launcher's environment this process
+                                                            starts the N ranks itself, as fresh child processes)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1 under a launcher)
 
 Metric (BASELINE.json): batched FWHT Gtransforms/s (one transform = one length-D row) with the
 achieved HBM GB/s against the roofline.  Workload = the configuration the metric's target is
@@ -54,13 +55,38 @@ def parse():
     return ap.parse_args()
 
 
+def self_launch(n_gpus):
+    """``python bench.py --gpus N`` typed without a launcher (no WORLD_SIZE in the environment): start the N ranks as
+    FRESH CHILD PROCESSES through torch.distributed.run -- before this process has touched the GPU (nothing above calls
+    torch.cuda / HIP; a child, never an exec of this process) -- pass rank 0's single JSON line through on stdout and
+    return the launcher's exit code.  The children see WORLD_SIZE and take the under-a-launcher path."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"[bench] --gpus {n_gpus} without a launcher: starting {n_gpus} ranks: {' '.join(cmd)}")
+    child = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)           # stderr passes through
+    lines = [ln for ln in child.stdout.splitlines() if ln.startswith("{")]
+    for ln in child.stdout.splitlines():
+        if not ln.startswith("{"):
+            log(ln)
+    if lines:
+        print(lines[-1], flush=True)
+    if child.returncode == 0 and not lines:
+        log("[bench] the ranks exited 0 without a JSON line")
+        return 1
+    return child.returncode
+
+
 def setup_dist(n_gpus):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != n_gpus:
-        raise SystemExit(f"bench.py: --gpus {n_gpus} but WORLD_SIZE={world}; for N > 1 launch with "
-                         "python -m torch.distributed.run --nproc-per-node N")
+        raise SystemExit(f"bench.py: --gpus {n_gpus} but WORLD_SIZE={world}")
     if CPU_PLUMBING:
         device = torch.device("cpu")
     else:
@@ -134,11 +160,16 @@ def timed(step, steps, warmup, device, world):
         torch.cuda.synchronize(device)
     wall = time.perf_counter() - t0
     ev_ms = ev0.elapsed_time(ev1) / steps if use_ev else wall * 1e3 / steps
+    per_rank = None
     if world > 1:
-        t = torch.tensor([wall], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
-    return wall, ev_ms
+        # every rank's own numbers (wall incl. the closing barrier, and its kernel time), not only the maximum
+        mine = torch.tensor([wall * 1e3 / steps, ev_ms], dtype=torch.float64, device=device)
+        both = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(both, mine)
+        per_rank = {"ms_per_step_wall": [round(float(b[0]), 4) for b in both],
+                    "ms_per_step_kernel_events": [round(float(b[1]), 4) for b in both]}
+        wall = max(float(b[0]) for b in both) * steps / 1e3
+    return wall, ev_ms, per_rank
 
 
 def event_ms(fn, iters=10, warm=2, warm_ms=0.0):
@@ -650,6 +681,17 @@ def _timed_all_ranks(fn, iters, device):
     return float(t.item())
 
 
+def _same_on_all_ranks(t, device):
+    """(every rank holds the same bits of ``t``, this rank's sha256 of them)"""
+    import hashlib
+    digest = hashlib.sha256(t.detach().cpu().contiguous().numpy().tobytes()).hexdigest()
+    word = torch.tensor([int(digest[:15], 16)], dtype=torch.int64, device=device)
+    lo, hi = word.clone(), word.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    return bool(lo.item() == hi.item()), digest
+
+
 def multi_gpu_extras(device, rank, world, small=False):
     """N > 1 only, every rank takes part: BASELINE config 5 (D = 4096 fp16, 2^20 rows in total, row-sharded: the
     strong-scaling curve) and config 4 (WHVIRegression 3 -> 1024 -> 1024 -> 1, 128 MC samples sharded over the
@@ -704,14 +746,18 @@ def multi_gpu_extras(device, rank, world, small=False):
     except Exception as e:                      # noqa: BLE001
         err = repr(e)
     if _all_ok(net is not None, device):
-        shape = []
+        shape, keep = [], [None]
 
         def predict():
             with torch.no_grad():
-                shape[:] = list(mc_sharded_forward(net, xb, n_mc, base_seed=1).shape)
+                keep[0] = mc_sharded_forward(net, xb, n_mc, base_seed=1)
+                shape[:] = list(keep[0].shape)
         ms = _timed_all_ranks(predict, 3, device)
+        same, digest = _same_on_all_ranks(keep[0], device)
+        keep[0] = None
         out["whviregression_3_1024_1024_1_mc128_sharded"] = {
             "ms": round(ms, 3), "prediction_shape": shape, "mc_samples_per_gpu": n_mc // world,
+            "gathered_predictions_sha256_rank0": digest, "gathered_predictions_identical_on_all_ranks": same,
             "config": f"batch {batch} x 3, {n_mc} MC samples sharded over {world} ranks, one all-gather of "
                       f"(batch, 1, {n_mc // world}) blocks per forward, fp32, eval"}
     else:
@@ -753,8 +799,52 @@ def multi_gpu_extras(device, rank, world, small=False):
     return out
 
 
+def device_identity(device):
+    """What distinguishes this rank's device from the others': the GPU's uuid and PCI address (host name + pid in the CPU
+    plumbing mode of the tests)."""
+    import socket
+    if device.type != "cuda":
+        return f"cpu:{socket.gethostname()}:pid{os.getpid()}"
+    p = torch.cuda.get_device_properties(device)
+    uuid = getattr(p, "uuid", None)
+    pci = ":".join(f"{getattr(p, k):02x}" for k in ("pci_domain_id", "pci_bus_id", "pci_device_id") if hasattr(p, k))
+    return f"cuda:{device.index} uuid={uuid} pci={pci} {p.name}"
+
+
+def sharded_prediction_check(device, rank, world):
+    """N > 1, always: the one exchange step of the path -- MC samples sharded over the ranks, ONE all-gather of the predictions
+    (src/networks.py:47-51,112-114 is the single-process loop + reduction being sharded) -- on a small network.  Every rank
+    checksums the gathered (batch, 1, S) tensor; the line reports rank 0's and whether all ranks computed the same bits,
+    and that rank r's block of samples is what rank r alone computed."""
+    import torch.nn as nn
+    from whvi_amd.layers import WHVILinear
+    from whvi_amd.networks import WHVIRegression
+    from whvi_amd.parallel import mc_sharded_forward, shard_bounds
+    n_mc = 4 * world
+    torch.manual_seed(11)                           # replicated parameters and input
+    net = WHVIRegression([WHVILinear(3, 64), nn.ReLU(), WHVILinear(64, 64), nn.ReLU(), WHVILinear(64, 1)],
+                         eval_samples=n_mc)
+    with torch.no_grad():                           # the initial s1, s2 ~ 0.01 N(0, 1) give outputs of ~1e-9: scale them up
+        for name, p_ in net.named_parameters():
+            if name.rsplit(".", 1)[-1] in ("s1", "s2"):
+                p_.mul_(30.0)
+    net = net.to(device).eval()
+    xb = torch.randn(33, 3).to(device)
+    with torch.no_grad():
+        pred = mc_sharded_forward(net, xb, n_mc, base_seed=5)          # (33, 1, n_mc), identical on every rank
+    same, digest = _same_on_all_ranks(pred, device)
+    b, e = shard_bounds(n_mc, rank, world)
+    spread = float(pred.std(dim=2).mean())           # the samples differ (ranks did not all draw the same eps)
+    return {"prediction_shape": list(pred.shape), "sha256_rank0": digest, "identical_on_all_ranks": same,
+            "mc_samples": n_mc, "samples_of_rank0": [b, e], "values_finite": bool(torch.isfinite(pred).all()),
+            "mean_std_over_samples": spread,
+            "what": "WHVIRegression 3->64->64->1, batch 33, MC samples sharded over the ranks, one all-gather"}
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
     rank, world, device = setup_dist(args.gpus)
     d = 1 << args.log2d
     rows = args.rows if not CPU_PLUMBING else 256
@@ -770,7 +860,7 @@ def main():
     x.mul_(2.0 ** scale_log2)
     step = make_step(x)
 
-    wall, ev_ms = timed(step, args.steps, args.warmup, device, world)
+    wall, ev_ms, per_rank = timed(step, args.steps, args.warmup, device, world)
     finite = bool(torch.isfinite(x[:: max(1, rows // 64)]).all())
     if device.type == "cuda":
         kernel_symbol = _hip.last_kernel()       # what the library's dispatch actually launched for this shape
@@ -815,6 +905,19 @@ def main():
         multi = multi_gpu_extras(device, rank, world)
         if rank == 0:
             rec["extras_multi_gpu"] = multi
+    if world > 1:
+        # the line proves what ran: every rank's device, every rank's time, and a checksum of the gathered predictions
+        seen = [None] * world
+        dist.all_gather_object(seen, device_identity(device))
+        try:
+            check = sharded_prediction_check(device, rank, world)
+        except Exception as err:                      # noqa: BLE001  (a report, never a reason to lose the line)
+            check = {"error": repr(err)}
+        if rank == 0:
+            rec["ranks_seen"] = seen
+            rec["distinct_devices"] = len(set(seen))
+            rec["per_rank"] = per_rank
+            rec["sharded_prediction_check"] = check
     if world > 1 and rank == 0:
         # what the collectives actually ran on: the backend torch.distributed reports ("nccl" is RCCL on ROCm)
         rec["distributed"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),

@@ -216,7 +216,31 @@ def _train_worker(rank, world, port, tmp):
         dist.all_gather(both, flat)
         assert torch.equal(both[0], both[1])
         with pytest.raises(RuntimeError, match="cannot be combined"):
-            net.train_model(loader, optimizer, scheduler, epochs1=0, epochs2=0, graphed=True)
+            net.train_model(loader, optimizer, scheduler, epochs1=0, epochs2=0, graphed=True, sharded=True)
+        # ---- fewer samples than ranks.  Rank 1 holds NO sample; with ignore_kl its loss share has no graph --
+        # it must skip backward() and still join the gradient all-reduce (zeros), not raise while rank 0 waits inside it
+        for ignore_kl in (True, False):
+            opt.zero_grad(set_to_none=True)
+            total = parallel.mc_sharded_loss(net, x, y, n=120, n_samples=1, base_seed=9, ignore_kl=ignore_kl)
+            with torch.random.fork_rng(devices=[]):
+                torch.manual_seed(parallel.sample_seed(9, 0))
+                out = net.sequential(x)
+            want = net.likelihood.mnll_batch_estimate(y, out.reshape(12, 1, 1), 120) + (0.0 if ignore_kl else net.kl)
+            assert abs(float(total) - float(want)) <= 1e-6 * abs(float(want)), (ignore_kl, float(total), float(want))
+            grads = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+            both = [torch.zeros_like(grads) for _ in range(world)]
+            dist.all_gather(both, grads)
+            assert torch.equal(both[0], both[1]) and float(grads.abs().max()) > 0
+        # ... and train_model does not switch to sample sharding by itself when there is less than one sample per rank (the
+        # default train_samples = 1: a data-parallel caller feeding each rank its own batches keeps its behaviour)
+        net.train_samples = 1
+        calls.clear()
+        parallel.all_reduce_grads = lambda module, average=True: (calls.append(average), real(module, average))[1]
+        try:
+            net.train_model(loader, optimizer, scheduler, epochs1=1, epochs2=0)
+        finally:
+            parallel.all_reduce_grads = real
+        assert calls == [], calls
         open(os.path.join(tmp, f"train_ok{rank}"), "w").write("ok")
     finally:
         dist.destroy_process_group()
@@ -253,3 +277,34 @@ def test_bench_two_ranks_gloo_cpu_plumbing(tmp_path):
     assert sharded["prediction_shape"] == [16, 1, 4] and sharded["mc_samples_per_gpu"] == 2 and sharded["ms"] > 0
     # the line says which backend and how many ranks the collectives saw
     assert rec["distributed"]["backend"] == "gloo" and rec["distributed"]["world_size"] == 2
+
+
+def test_bench_plain_command_starts_its_own_ranks(tmp_path):
+    """``python bench.py --gpus 2`` as typed -- no launcher, no WORLD_SIZE: bench.py starts the two ranks itself as child
+    processes (torch.distributed.run), passes rank 0's ONE JSON line through and exits with the children's code.  The
+    line proves what ran: one entry per rank in ``ranks_seen`` (distinct devices / processes), every rank's own time,
+    and a checksum of the all-gathered predictions that all ranks computed identically (CPU plumbing mode: gloo)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["WHVI_BENCH_CPU_PLUMBING"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                         env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), out.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["value"] > 0
+    assert len(rec["ranks_seen"]) == 2 and rec["distinct_devices"] == 2
+    assert len(rec["per_rank"]["ms_per_step_wall"]) == 2 and all(v > 0 for v in rec["per_rank"]["ms_per_step_wall"])
+    assert abs(max(rec["per_rank"]["ms_per_step_wall"]) - rec["ms_per_step"]) < 1e-3
+    check = rec["sharded_prediction_check"]
+    assert check["identical_on_all_ranks"] is True and check["prediction_shape"] == [33, 1, 8] and check["values_finite"]
+    assert check["mean_std_over_samples"] > 0 and len(check["sha256_rank0"]) == 64
+    assert rec["extras_multi_gpu"]["whviregression_3_1024_1024_1_mc128_sharded"]["gathered_predictions_identical_on_all_ranks"] is True
+    # a failing rank is an exit code, not a silent success: an impossible row shape makes the ranks raise
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                          "--log2d", "-3"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0 and not [ln for ln in bad.stdout.splitlines() if ln.startswith("{")]

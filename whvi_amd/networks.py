@@ -221,14 +221,17 @@ class WHVINetwork(nn.Module, WHVI):
         many batch shapes get a captured step of their own -- the full batch and a short last one; further shapes take the
         eager step.  Returns the captured step of the first batch shape (``None`` when not graphed).
 
-        ``sharded`` (not in the reference, which is single-process): ``None`` = automatically when a ``torch.distributed``
-        process group is initialised, ``True`` / ``False`` to force.  The ``train_samples`` Monte-Carlo samples of every
+        ``sharded`` (not in the reference, which is single-process): ``True`` / ``False`` to force; ``None`` = automatically,
+        and only where sharding cannot change what an existing caller gets: inside an initialised ``torch.distributed``
+        process group, NOT graphed, and with at least one Monte-Carlo sample per rank (``train_samples >= world`` -- with
+        the default ``train_samples = 1`` a data-parallel job that feeds every rank its own batches keeps doing exactly
+        that).  The ``train_samples`` Monte-Carlo samples of every
         step are then split over the ranks (``whvi_amd.parallel.mc_sharded_loss``): each rank runs the SAME batch --
         feed every rank the same data -- for its share of the samples, gradients are summed in one all-reduce, and the
         replicated parameters stay bit-equal across ranks.  Step k draws from generators seeded with (k, rank)."""
         if sharded is None:
             from whvi_amd import parallel
-            sharded = parallel._in_group()
+            sharded = (not graphed) and parallel._in_group() and self.train_samples >= parallel._world()[1]
         if sharded and graphed:
             raise RuntimeError("train_model: graphed=True and sharded=True cannot be combined (the gradient all-reduce is "
                                "not part of the captured step)")

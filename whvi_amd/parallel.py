@@ -239,8 +239,12 @@ def mc_sharded_loss(net, x: torch.Tensor, y: torch.Tensor, n: int, n_samples: in
             torch.manual_seed(sample_seed(base_seed, rank))
             seed_inkernel_rng(net, base_seed, rank)
         net._pass_kl = None
-        pred = _local_predictions(net, x, n_local)
-        mnll = net.likelihood.mnll_batch_estimate(y, pred, n) if n_local > 0 else pred.sum() * 0.0
+        if n_local > 0:
+            pred = _local_predictions(net, x, n_local)
+            mnll = net.likelihood.mnll_batch_estimate(y, pred, n)
+        else:
+            # a rank without samples (n_samples < world): no network pass at all; its share of the loss is KL / world
+            pred, mnll = None, torch.zeros((), dtype=x.dtype, device=x.device)
         pass_kl, net._pass_kl = getattr(net, "_pass_kl", None), None
         local = mnll * (n_local / float(n_samples))
         kl = None
@@ -252,7 +256,10 @@ def mc_sharded_loss(net, x: torch.Tensor, y: torch.Tensor, n: int, n_samples: in
         net.current_kl = kl.detach() if torch.is_tensor(kl) else kl
     if not backward:
         return local
-    local.backward()
+    if local.requires_grad:
+        local.backward()
+    # (else: no samples here and ignore_kl -- nothing to differentiate; this rank still JOINS the all-reduce below with
+    # zero gradients: a rank that skipped it would leave the others blocked inside the collective)
     total = local.detach().clone()
     del local, mnll, pred                                    # no graph of this pass outlives it
     all_reduce_grads(net, average=False)
