@@ -73,6 +73,12 @@ int         whvi_max_log2d(int32_t dtype);  /* largest supported log2(D): 24 for
                                              * longer rows take extra high-bit passes), 16 for f16/bf16
                                              * (single pass only: one rounding)                        */
 
+/* Measurement aid (no counterpart in the reference): a copy of `bytes` bytes (a multiple of 16; dst == src allowed) with the
+ * streaming geometry of the transform kernels and no arithmetic -- one 16 KiB tile per wave, 256-thread blocks,
+ * XCD-contiguous block order, non-temporal loads, block barrier, write-through non-temporal stores.  Its rate is the
+ * ceiling this memory system offers the access pattern whvi_fwht_* uses; bench.py prints it as roofline.ceiling_measured. */
+int whvi_stream_copy_probe(void *dst, const void *src, int64_t bytes, void *stream);
+
 /* Batched row FWHT: dst[r, :] = FWHT(src[r, :]) for r in [0, rows).
  * Replaces fwht_cuda_frontend (fwht_cuda_kernel.cu:156-181) + the X.clone() of
  * fwht_cuda.cpp:11 (pass dst != src for the reference's out-of-place semantics).

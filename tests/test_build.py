@@ -59,3 +59,74 @@ def test_setup_py_builds_an_installable_tree(tmp_path):
     run = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=str(tmp_path),
                          env={**os.environ, "PYTHONPATH": str(lib)})
     assert run.returncode == 0, run.stderr[-2000:]
+
+
+# ---- what the SHIPPED binary contains (tools/shipped_isa.py: metadata + disassembly of libwhvi_hip.so's gfx950 code objects)
+# kernel (as rocprofv3 prints it; the instantiations profiles/hbm_traffic.json and DESIGN.md's tables publish numbers for),
+# VGPR budget of the occupancy it was tuned at (waves per SIMD = 512 // VGPRs: 128 -> 4, 168 -> 3), store mnemonic of its
+# streaming path, and how those stores must be issued: "spaced" = at most 6 of them in back-to-back groups (the read + write streams: the
+# headline runs 6.44 TB/s with one instruction between its 16 stores and 5.89 with them back to back, kernels.hpp /
+# profiles/r03/rows_store_issue_ab.log), "adjacent" = runs of >= 3 (the write-only streams, where spacing LOSES 6-9 %:
+# wbar_fwd.hpp, profiles/r03/write_stream_store_form_ab.log)
+ISSUE_CONTRACTS = [
+    ("whvi::fwht_rows_kernel<float, 12, 16, 0, false, true, 256, 1, false>", 128, "buffer_store_dwordx4", "spaced"),    # the headline
+    ("whvi::fwht_rows_kernel<float, 11, 16, 0, false, true, 256, 1, true>", 128, "buffer_store_dwordx4", "spaced"),
+    ("whvi::fwht_rows_kernel<float, 9, 16, 0, false, true, 256, 1, true>", 128, "buffer_store_dwordx4", "spaced"),
+    ("whvi::fwht_rows_kernel<__half, 12, 8, 2, false, true, 256, 1, false>", 128, "buffer_store_dwordx4", "spaced"),    # config 5
+    ("whvi::fwht_rows_kernel<float, 13, 32, 0, false, true, 256, 1, false>", 168, "buffer_store_dwordx4", "spaced"),    # three waves per SIMD
+    ("whvi::fused_shs_kernel<float, 11, 16, 1, false, true, 256, 0, 1, false, false>", 168, "buffer_store_dwordx4", "spaced"),   # config 3
+    ("whvi::fused_shs_kernel<float, 12, 16, 1, false, true, 256, 0, 1, false, false>", 168, "buffer_store_dwordx4", "spaced"),
+    ("whvi::wbar_fwd_kernel<float, 11, 16, true, false>", 128, "global_store_dwordx4", "adjacent"),
+    ("whvi::wbar_fwd_kernel<float, 9, 16, true, false>", 128, "global_store_dwordx4", "adjacent"),
+    ("whvi::diag_apply_kernel<float, 9, 16, true, true>", 128, "global_store_dwordx4", "adjacent"),                    # config 2's layer, shared input
+    ("whvi::diag_apply_kernel<float, 10, 16, true, false>", 128, "buffer_store_dwordx4", "spaced"),                     # config 4's middle layer
+    ("whvi::stream_copy_kernel<16, 256>", 128, "buffer_store_dwordx4", "spaced"),                                       # the measured ceiling
+]
+
+
+def _issue_violations(shipped, contracts):
+    from shipped_isa import store_runs
+    bad = []
+    for name, budget, mnemonic, form in contracts:
+        k = shipped.find(name)
+        if k["scratch"] != 0:
+            bad.append(f"{name}: {k['scratch']} B of scratch")
+        if k["vgprs"] + k["agprs"] > budget:
+            bad.append(f"{name}: {k['vgprs']} + {k['agprs']} registers > {budget} (occupancy budget)")
+        runs = store_runs(shipped.ops(name), mnemonic)
+        if sum(runs) < 8:
+            bad.append(f"{name}: no {mnemonic} stream found ({runs})")
+        elif form == "spaced" and sum(r for r in runs if r > 1) > 6:       # (the compiler pairs the first two / last three)
+            bad.append(f"{name}: {mnemonic} issued back to back in runs of {runs}")
+        elif form == "adjacent" and max(runs) < 3:
+            bad.append(f"{name}: {mnemonic} issued apart ({runs}); this write-only stream wants them back to back")
+    return bad
+
+
+def test_shipped_kernels_keep_their_occupancy_and_store_issue_form(tmp_path):
+    """nothing enforced the instruction-issue rules the last 9 % rests on.  Reads the shipped library
+    (no GPU, no recompilation): every kernel a PMC record names exists, none uses scratch, and the published
+    instantiations keep their register budget and the issue pattern of their 16-byte stores.  The check is proven able to
+    fail: the same kernel built with -DWHVI_ROWS_STORE_FORM=1 (chunk offsets as scalar offsets: the stores go out back to
+    back, 5.89 instead of 6.44 TB/s) violates the headline's contract."""
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from shipped_isa import ShippedLibrary
+    with ShippedLibrary() as shipped:
+        assert len(shipped.kernels) > 1000
+        assert [n for n, k in shipped.kernels.items() if k["scratch"]] == []
+        records = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+        for key, rec in records.items():
+            if isinstance(rec, dict) and rec.get("kernel_symbol"):
+                shipped.find(rec["kernel_symbol"])                      # KeyError (with near misses) when it is gone
+        assert _issue_violations(shipped, ISSUE_CONTRACTS) == []
+    # a tuning build of the headline's translation unit with the back-to-back store form: the contract must catch it
+    obj = tmp_path / "fwht_f32_storeform1.o"
+    build = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
+                            "-fvisibility=hidden", "-DWHVI_TUNING_BUILD", "-DWHVI_ROWS_STORE_FORM=1", "-c",
+                            os.path.join(ROOT, "whvi_amd", "csrc", "fwht_f32.hip"), "-o", str(obj)],
+                           capture_output=True, text=True, timeout=1200)
+    assert build.returncode == 0, build.stderr[-2000:]
+    with ShippedLibrary(str(obj)) as tuned:
+        bad = _issue_violations(tuned, ISSUE_CONTRACTS[:1])
+    assert len(bad) == 1 and "back to back" in bad[0], bad

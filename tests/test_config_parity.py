@@ -351,10 +351,21 @@ def test_one_launch_schedule_is_the_reference_schedule_gpu(hip_lib):
         _hip.decay_lr_step(torch.zeros((), device="cuda"), torch.zeros((), device="cuda"), 1.0, 1.0, 1.0, 1.0)   # t not float64
 
 
+@pytest.fixture
+def warn_always():
+    """torch's C++ warnings fire once per process unless warn-always is on: a test that promotes one to an error must not
+    depend on no earlier test having used up the single emission."""
+    before = torch.is_warn_always_enabled()
+    torch.set_warn_always(True)
+    yield
+    torch.set_warn_always(before)
+
+
 @pytest.mark.gpu
+@pytest.mark.filterwarnings("error:The AccumulateGrad node's stream does not match:UserWarning")
 @pytest.mark.parametrize("packed", [False, True])
 @pytest.mark.parametrize("run", ["default", "fast"])
-def test_train_trajectory_graphed_vs_reference_gpu(run, packed, tmp_path, hip_lib, dataflow):
+def test_train_trajectory_graphed_vs_reference_gpu(run, packed, tmp_path, hip_lib, dataflow, warn_always):
     """The reference's training recipe on the FAST path: ``train_model(graphed=True)`` -- both phases,
     ``scheduler.step()`` after every batch (src/networks.py:80-81), the checkpoint of phase 2 -- with every step one
     hipGraph replay holding loss, backward, Adam and the schedule (learning rate and step counter in device memory).

@@ -554,3 +554,28 @@ def test_one_row_tiles_of_128_registers_at_streaming_size(dtype, log2d, K, hip_l
         _hip.fwht_rows(x, out=x)
         assert torch.equal(x[idx].to(torch.int64), ints[idx].to(torch.int64) * d)
         assert torch.equal(x[-1].to(torch.int64), ints[-1].to(torch.int64) * d)
+
+
+def test_config1_shape_on_the_gpu_box(hip_lib):
+    """BASELINE config 1 at exactly its shape -- (1024, 512) fp32, benchmarks/walsh.py:14-21 -- on the GPU box: the device
+    path (``fwht_cuda.fwht`` -> whvi_fwht_f32) AND the host library (``fwht_cpp.forward`` -> libwhvi_cpu.so, checked on THIS
+    box's CPU) both bit-equal to the C oracle (restatement of src/fwht/cpp/fwht.cpp:3-21) and, where its binary travelled,
+    to the reference's own compiled FWHT (oracle/_ref)."""
+    import fwht_cpp
+    import fwht_cuda
+    g = torch.Generator().manual_seed(1024 * 512)
+    x = torch.randn(1024, 512, generator=g)
+    want = oracle.fwht(x.numpy())
+    dev = fwht_cuda.fwht(x.to(DEV))
+    assert dev.shape == (1024, 512) and dev.dtype == torch.float32
+    assert np.array_equal(dev.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    host = fwht_cpp.forward(x)
+    assert np.array_equal(host.numpy().view(np.uint32), want.view(np.uint32))
+    ref = oracle.load_reference_cpp()
+    if ref is not None:
+        assert np.array_equal(ref.forward(x).numpy().view(np.uint32), want.view(np.uint32))
+    # integer-valued input: exact on every path (north_star: bit-exact on integer inputs)
+    xi = torch.randint(-8, 8, (1024, 512), generator=g)
+    wi = oracle.fwht(xi.to(torch.int32).numpy())
+    assert np.array_equal(fwht_cuda.fwht(xi.float().to(DEV)).cpu().numpy(), wi.astype(np.float32))
+    assert np.array_equal(fwht_cpp.forward(xi.float()).numpy(), wi.astype(np.float32))

@@ -96,6 +96,8 @@ def _declare_f3(lib):
         fn = getattr(lib, "whvi_diag_apply_bwd_" + sfx)
         fn.restype = ctypes.c_int
         fn.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, ctypes.c_int32, i64, ctypes.c_int32, vp]
+    lib.whvi_stream_copy_probe.restype = ctypes.c_int
+    lib.whvi_stream_copy_probe.argtypes = [vp, vp, i64, vp]
     lib.whvi_diag_apply_bwd_slabs.restype = ctypes.c_int64
     lib.whvi_diag_apply_bwd_slabs.argtypes = [ctypes.c_int32, i64, i64, ctypes.c_int32]
 
@@ -211,6 +213,21 @@ def fwht_rows(src: torch.Tensor, out: torch.Tensor = None, variant: int = None) 
             rc = L.whvi_fwht_ex(out.data_ptr(), src.data_ptr(), rows, log2d,
                                 _DTYPE_CODE[src.dtype], int(variant), _stream(src))
     _check(rc, "whvi_fwht")
+    return out
+
+
+def stream_copy_probe(src: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+    """whvi_stream_copy_probe: copy ``src`` (contiguous, a multiple of 16 bytes) with the transform kernels' streaming
+    geometry and no arithmetic; ``out`` may be ``src`` (in place).  A measurement aid (bench.py: roofline.ceiling_measured)."""
+    if src.device.type != "cuda" or not src.is_contiguous():
+        raise RuntimeError("stream_copy_probe: contiguous CUDA tensor expected")
+    if out is None:
+        out = torch.empty_like(src)
+    elif not out.is_contiguous() or out.numel() * out.element_size() != src.numel() * src.element_size() or out.device != src.device:
+        raise RuntimeError("stream_copy_probe: out must match src")
+    with _OnDevice(src.device):
+        rc = lib().whvi_stream_copy_probe(out.data_ptr(), src.data_ptr(), src.numel() * src.element_size(), _stream(src))
+    _check(rc, "whvi_stream_copy_probe")
     return out
 
 

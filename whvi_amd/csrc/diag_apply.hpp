@@ -234,9 +234,12 @@ diag_apply_kernel(u32x4 *__restrict__ dst, const u32x4 *x, const T *__restrict__
         if constexpr (XSHARED) {                // write-only stream: back-to-back non-temporal global stores (wbar_fwd.hpp)
 #pragma unroll
             for (int k = 0; k < K; ++k) st16<true>(dst + tile0 + k * 64 + lane, E::pack(r[k]));
-        } else {                                // read + write stream: write-through non-temporal buffer stores (kernels.hpp)
-#pragma unroll
-            for (int k = 0; k < K; ++k) tile_store_stream(dst + tile0, lane, k, E::pack(r[k]), TILE * 16);
+        } else {                                // read + write stream: write-through non-temporal buffer stores, one issue
+#pragma unroll                                  // slot apart (kernels.hpp: back to back they cost the headline stream 9 %)
+            for (int k = 0; k < K; ++k) {
+                tile_store_stream(dst + tile0, lane, k, E::pack(r[k]), TILE * 16);
+                asm volatile("s_nop 0");
+            }
         }
     } else {
 #pragma unroll
