@@ -194,11 +194,21 @@ class GraphedTrainStep:
         torch.cuda.set_rng_state(saved_rng, dev)
         self._eps_owners = [(m, m._eps_static) for m in net.modules() if torch.is_tensor(getattr(m, "_eps_static", None))]
         self.eps_buffers = [buf for _, buf in self._eps_owners]
+        # the warm-up must leave no autograd graph -- hence no gradient accumulator of ITS stream -- behind: the capture's
+        # forward would pick those accumulators up again (they live as long as any graph references them) and its backward,
+        # on the capture stream, would then synchronise with the warm-up's stream inside the capture
+        net._pass_kl = None
+        for module in net.modules():
+            if hasattr(module, "_mc_kl"):
+                module._mc_kl = None
+        optimizer.zero_grad(set_to_none=True)
+        gc.collect()
+        left_behind = _stale_graph_holders(params, dev)
         stale = [w for w in caught if "AccumulateGrad node's stream" in str(w.message)]
         for w in caught:                             # everything else is passed on unchanged
             if w not in stale:
                 warnings.warn_explicit(w.message, w.category, w.filename, w.lineno)
-        if stale:
+        if stale or left_behind:
             optimizer.zero_grad(set_to_none=True)
             raise RuntimeError(stale_message)
         self.graph = torch.cuda.CUDAGraph()

@@ -70,6 +70,10 @@ class WHVILinear(nn.Module, WHVI):
         """``n_samples`` stochastic passes at once: (batch, n_in) or (n_samples, batch, n_in) ->
         (n_samples, batch, n_out).  Used by ``WHVINetwork`` instead of its per-sample loop."""
         out = self.weight_submodule.forward_mc(x, n_samples)
-        # KL of exactly this pass when the fused reparameterisation kernel produced it (GPU), else None
+        # KL of exactly this pass when the fused reparameterisation kernel produced it (GPU), else None.  MOVED, not copied:
+        # the tensor carries this pass's autograd graph, and a second reference on the inner module would keep that graph --
+        # and the parameters' gradient accumulators, created on whatever stream ran this pass -- alive until the NEXT pass
+        # (round 3: the accumulators of GraphedTrainStep's side-stream warm-up survived into the capture this way)
         self._mc_kl = getattr(self.weight_submodule, "_mc_kl", None)
+        self.weight_submodule._mc_kl = None
         return out
