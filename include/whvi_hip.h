@@ -31,7 +31,10 @@
  * Transform definition: unnormalised Walsh-Hadamard transform in natural (Sylvester)
  * order of every row, y = x . H_D, computed as the radix-2 butterfly network in ASCENDING
  * stride order (h = 1, 2, 4, ...) with plain add/sub -- the order of src/fwht/cpp/fwht.cpp:7-18,
- * so f32/f64 results are bit-identical to that reference and integer results are exact.
+ * so f32/f64 results of whvi_fwht_<dtype> are bit-identical to that reference (sign of zero included, at every size) and
+ * integer results are exact.  Two opt-in forms trade the sign of a ZERO result for speed and say so where they are declared:
+ * whvi_fwht_ex with WHVI_FWHT_SIGNED_LANES, and the fused pipelines whvi_fused_shs_* (a result that is -0 in the reference's
+ * arithmetic may come back as +0; every other bit, NaN positions included, is the reference's).
  */
 #ifndef WHVI_HIP_H
 #define WHVI_HIP_H
@@ -83,14 +86,10 @@ int whvi_stream_copy_probe(void *dst, const void *src, int64_t bytes, void *stre
  * Replaces fwht_cuda_frontend (fwht_cuda_kernel.cu:156-181) + the X.clone() of
  * fwht_cuda.cpp:11 (pass dst != src for the reference's out-of-place semantics).
  *
- * Sign of zero (f32 / f64; every other bit of every result, NaN positions included, is independent of the launch form):
- * the streaming launches (buffers beyond the 256 MiB Infinity Cache) of whvi_fwht_f32 for D = 512 .. 2048 and of
- * whvi_fwht_f64 for D = 64 .. 2048, and both fused pipelines, run their lane stages as fused multiply-adds by +/-1,
- * through which a zero carries no sign.  A result that
- * is NEGATIVE zero in the reference's arithmetic (-0 + -0: element 0 of a row made of negative zeros only) may therefore
- * come back as +0 from those launches while the cache-resident launch of the same call returns -0; exact cancellations are +0
- * either way.  Callers that compare raw bits across batch sizes should compare zeros by value
- * (tests/test_fwht_gpu.py::test_negative_zero_contract_of_both_launch_forms). */
+ * Sign of zero: none to mention -- these entry points run the plain add / sub butterfly network at EVERY size, so f32 / f64
+ * results carry the reference's bits including the sign of a zero result (a row of negative zeros gives [-0, +0, +0, ...],
+ * as -0 + -0 = -0 does in src/fwht/cpp/fwht.cpp:11-13), whatever the launch form (cache-resident, streaming, block per row).
+ * The faster lane-stage form that loses that sign is opt-in: WHVI_FWHT_SIGNED_LANES of whvi_fwht_ex below. */
 int whvi_fwht_f32 (void *dst, const void *src, int64_t rows, int32_t log2d, void *stream);
 int whvi_fwht_f64 (void *dst, const void *src, int64_t rows, int32_t log2d, void *stream);
 int whvi_fwht_f16 (void *dst, const void *src, int64_t rows, int32_t log2d, void *stream);
@@ -115,10 +114,18 @@ int whvi_fwht_i32 (void *dst, const void *src, int64_t rows, int32_t log2d, void
  *                 1  2^12-element pieces + high-bit passes for every long row (round 1's form)
  *                 2  one row per block      3  persistent pipelined grid (where that instantiation exists)
  *                 4  as 1 with every pass over the whole buffer instead of 128 MiB row groups
+ *   bit 23 (WHVI_FWHT_SIGNED_LANES), with bits 0..19 zero: the production launch of whvi_fwht_<dtype>, except that STREAMING
+ *                 launches (buffers beyond the 256 MiB Infinity Cache) of f32 rows of D = 512 .. 2048 and f64 rows of
+ *                 D = 64 .. 2048 run their lane stages as fused multiply-adds by +/-1 (6.42 vs 6.31 TB/s, +1.7 %).  A zero
+ *                 carries no sign through those: a result that is NEGATIVE zero in the reference's arithmetic (element 0 of a
+ *                 row of negative zeros) comes back as +0; every other bit is unchanged
+ *                 (tests/test_fwht_gpu.py::test_negative_zero_contract_of_both_launch_forms).  Other shapes ignore the bit.
  * Variants other than the ds_bpermute cross-check exist for f32 and D = 512..4096 only; elsewhere only
- * bit 0 (and bits 20..22) are honoured.  All variants produce identical bits (tests/test_fwht_gpu.py).
+ * bit 0 (and bits 20..23) are honoured.  All variants produce identical bits, WHVI_FWHT_SIGNED_LANES up to the sign of zero
+ * (tests/test_fwht_gpu.py).
  * The library reads NO environment variables: its launch form is a function of its arguments.
  */
+#define WHVI_FWHT_SIGNED_LANES (1 << 23)
 int whvi_fwht_ex(void *dst, const void *src, int64_t rows, int32_t log2d,
                  int32_t dtype, int32_t variant, void *stream);
 

@@ -70,7 +70,9 @@ def test_setup_py_builds_an_installable_tree(tmp_path):
 # wbar_fwd.hpp, profiles/r03/write_stream_store_form_ab.log)
 ISSUE_CONTRACTS = [
     ("whvi::fwht_rows_kernel<float, 12, 16, 0, false, true, 256, 1, false>", 128, "buffer_store_dwordx4", "spaced"),    # the headline
-    ("whvi::fwht_rows_kernel<float, 11, 16, 0, false, true, 256, 1, true>", 128, "buffer_store_dwordx4", "spaced"),
+    ("whvi::fwht_rows_kernel<float, 11, 16, 0, false, true, 256, 1, false>", 128, "buffer_store_dwordx4", "spaced"),
+    ("whvi::fwht_rows_kernel<float, 9, 16, 0, false, true, 256, 1, false>", 128, "buffer_store_dwordx4", "spaced"),
+    ("whvi::fwht_rows_kernel<float, 11, 16, 0, false, true, 256, 1, true>", 128, "buffer_store_dwordx4", "spaced"),      # WHVI_FWHT_SIGNED_LANES
     ("whvi::fwht_rows_kernel<float, 9, 16, 0, false, true, 256, 1, true>", 128, "buffer_store_dwordx4", "spaced"),
     ("whvi::fwht_rows_kernel<__half, 12, 8, 2, false, true, 256, 1, false>", 128, "buffer_store_dwordx4", "spaced"),    # config 5
     ("whvi::fwht_rows_kernel<float, 13, 32, 0, false, true, 256, 1, false>", 168, "buffer_store_dwordx4", "spaced"),    # three waves per SIMD

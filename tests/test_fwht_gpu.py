@@ -320,9 +320,8 @@ def test_16bit_special_values(dtype, hip_lib):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 def test_float_special_values(dtype, hip_lib):
     """f32 / f64 rows holding subnormals, signed zeros, huge values (sums overflow), inf and NaN, through the cached
-    (unsigned network) and the streaming launches (f32 D = 2048: the SIGNED network) and the block-per-row kernel:
-    NaN in the same places as the oracle, every other value equal, and bit-identical wherever the oracle's value is not
-    a zero (the signed network's documented exception: a NEGATIVE zero result comes out as +0)."""
+    and the streaming launches and the block-per-row kernel: NaN in the same places as the oracle, every other value
+    equal, and bit-identical wherever the oracle's value is not a zero."""
     info = torch.finfo(dtype)
     specials = torch.tensor([0.0, -0.0, info.tiny, -info.tiny, info.tiny / 4, -info.tiny / 8, info.smallest_normal * 1.5,
                              info.max, -info.max, info.max / 2, 1.0, -1.0, float("inf"), -float("inf"), float("nan"), 3.0],
@@ -427,6 +426,8 @@ def test_last_kernel_names_the_launched_instantiation(hip_lib):
     assert _hip.last_kernel() == "whvi::fwht_rows_kernel<float, 12, 16, 0, false, false, 256, 0, false>"
     big = torch.zeros((1 << 29) // 2048 // 4 * 4, 2048, device=DEV)          # 512 MiB in place: streaming launch
     _hip.fwht_rows(big, out=big)
+    assert _hip.last_kernel() == "whvi::fwht_rows_kernel<float, 11, 16, 0, false, true, 256, 1, false>"
+    _hip.fwht_rows(big, out=big, signed_lanes=True)                         # opt-in: WHVI_FWHT_SIGNED_LANES
     assert _hip.last_kernel() == "whvi::fwht_rows_kernel<float, 11, 16, 0, false, true, 256, 1, true>"
     h = torch.zeros(1 << 14, 4096, device=DEV, dtype=torch.float16)
     _hip.fwht_rows(h, out=h)
@@ -464,10 +465,12 @@ def test_bench_line_on_the_gpu(hip_lib):
 @pytest.mark.parametrize("dtype,log2d", [(torch.float32, 9), (torch.float32, 10), (torch.float32, 11),
                                          (torch.float64, 6), (torch.float64, 9), (torch.float64, 11)])
 def test_signed_streaming_launch_of_f32_and_f64_rows(dtype, log2d, hip_lib):
-    """f32 streams of D = 512 .. 2048 and f64 streams of D = 64 .. 2048 beyond the Infinity Cache take the SIGNED DPP
-    network (one fma per lane-stage element, the tile carrying (-1)^popcount(lane & 15) until one repair multiply at the
-    end): 320 MiB in place, random floats and small integers, sampled rows bit-identical to the oracle -- and to the
-    unsigned network (a cached out-of-place launch of the same rows) -- and H.H = D.I exactly on the integers."""
+    """WHVI_FWHT_SIGNED_LANES (opt-in through whvi_fwht_ex): f32 streams of D = 512 .. 2048 and f64 streams of D = 64 .. 2048
+    beyond the Infinity Cache take the SIGNED DPP network (one fma per lane-stage element, the tile carrying
+    (-1)^popcount(lane & 15) until one repair multiply at the end): 320 MiB in place, random floats and small integers,
+    sampled rows bit-identical to the oracle -- and to the unsigned network (a cached out-of-place launch of the same
+    rows) -- and H.H = D.I exactly on the integers.  The DEFAULT launch of the same buffer (whvi_fwht_<dtype>) stays on
+    the unsigned network, and returns the same bits."""
     d = 1 << log2d
     esize = 4 if dtype == torch.float32 else 8
     name = "float" if dtype == torch.float32 else "double"
@@ -481,9 +484,12 @@ def test_signed_streaming_launch_of_f32_and_f64_rows(dtype, log2d, hip_lib):
         else:
             x = torch.randint(-3, 4, (rows, d), device=DEV, generator=g, dtype=torch.int32).to(dtype)
         keep = x[idx].clone()
-        _hip.fwht_rows(x, out=x)
+        plain = _hip.fwht_rows(x)[idx].cpu()                      # the drop-in entry point: unsigned network at every size
+        assert _hip.last_kernel().endswith(", false>") and ", false, true, " in _hip.last_kernel(), _hip.last_kernel()
+        _hip.fwht_rows(x, out=x, signed_lanes=True)
         assert _hip.last_kernel() == f"whvi::fwht_rows_kernel<{name}, {log2d}, 16, 0, false, true, 256, 1, true>", _hip.last_kernel()
         got = x[idx].cpu()
+        assert torch.equal(plain.view(bits), got.view(bits)), kind
         assert torch.equal(got.view(bits), _oracle(keep.cpu()).view(bits)), kind
         small = _hip.fwht_rows(keep)                              # 128 rows: the cached, unsigned launch
         assert _hip.last_kernel().endswith(", 0, false>") and ", false, false, " in _hip.last_kernel()
@@ -495,9 +501,10 @@ def test_signed_streaming_launch_of_f32_and_f64_rows(dtype, log2d, hip_lib):
 
 def test_negative_zero_contract_of_both_launch_forms(hip_lib):
     """include/whvi_hip.h, "Sign of zero": a row made of negative zeros only has the result [-0, +0, +0, ...] in the
-    reference's arithmetic (element 0 is a sum of negative zeros, -0 + -0 = -0; every difference -0 - -0 is +0).  The cache-resident launch and the unsigned network return exactly that; the signed streaming launch of
-    f32 rows of D = 512 .. 2048 returns +0 for those rows -- and ONLY that differs: every other row of the same buffer is
-    bit-identical between the two launch forms.  Fixed here so the divergence stays deliberate."""
+    reference's arithmetic (element 0 is a sum of negative zeros, -0 + -0 = -0; every difference -0 - -0 is +0).  The
+    drop-in entry point returns exactly that at EVERY size -- cache-resident launch and stream alike (round 4: one contract
+    for zero).  The opt-in WHVI_FWHT_SIGNED_LANES stream of f32 rows of D = 512 .. 2048 returns +0 for
+    those rows -- and ONLY that differs: every other row of the same buffer is bit-identical between the two forms."""
     d = 1024
     rows = (320 << 20) // (4 * d)
     x = torch.randn(rows, d, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))
@@ -509,7 +516,13 @@ def test_negative_zero_contract_of_both_launch_forms(hip_lib):
     assert bool((small[7] == 0).all()) and bool(torch.signbit(small[7, 0])) and not bool(torch.signbit(small[7, 1:]).any())
     assert not bool(torch.signbit(small[11]).any())
     assert torch.equal(small[7].cpu().view(torch.int32), _oracle(x[7:8].cpu())[0].view(torch.int32)), "reference arithmetic"
-    big = _hip.fwht_rows(x)                                         # 320 MiB out of place: signed streaming launch
+    plain = _hip.fwht_rows(x)                                       # 320 MiB out of place: the streaming launch, unsigned network
+    assert _hip.last_kernel() == "whvi::fwht_rows_kernel<float, 10, 16, 0, false, true, 256, 1, false>"
+    for r in (7, rows - 3):
+        assert torch.equal(plain[r].view(torch.int32), small[7].view(torch.int32)), "the reference's bits at every size"
+    assert torch.equal(plain[:16].view(torch.int32), small.view(torch.int32))
+    del plain
+    big = _hip.fwht_rows(x, signed_lanes=True)                      # opt-in: signed streaming launch
     assert _hip.last_kernel() == "whvi::fwht_rows_kernel<float, 10, 16, 0, false, true, 256, 1, true>"
     for r in (7, rows - 3):
         assert bool((big[r] == 0).all()) and not bool(torch.signbit(big[r]).any()), "documented exception: +0"

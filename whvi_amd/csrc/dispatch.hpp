@@ -142,8 +142,11 @@ void launch_wide_stream(u32x4 *d, const u32x4 *s, int64_t n_chunks, int64_t n_ti
 
 // variant word of whvi_fwht_ex: documented in include/whvi_hip.h (0 = production launch).
 // FULL = the extra tuning variants are compiled (f32, D = 512..4096).
+// signed_lanes (whvi_fwht_ex variant bit 23, WHVI_FWHT_SIGNED_LANES): the production launch, but streams of f32 rows of
+// 512 .. 2048 and f64 rows of 64 .. 2048 run their lane stages as signed fused multiply-adds (+1.7 %; a NEGATIVE zero result
+// comes back as +0).  whvi_fwht_<dtype> never sets it: its bits are the reference's at every size.
 template <typename T, int LOG2D, int K, bool FULL>
-inline void launch_rows(void *dst, const void *src, int64_t n_chunks, int variant, hipStream_t st)
+inline void launch_rows(void *dst, const void *src, int64_t n_chunks, int variant, hipStream_t st, bool signed_lanes = false)
 {
     constexpr bool SMALL_TILE = tile_vgprs<T, K>() <= 64;   // fits 1024-thread blocks / prefetch
     const int64_t n_tiles = (n_chunks + 64 * K - 1) / (64 * K);
@@ -176,8 +179,9 @@ inline void launch_rows(void *dst, const void *src, int64_t n_chunks, int varian
                 // fma per lane-stage element instead of a sign fold + an add, one repair multiply at the end): 6.35-6.38 vs
                 // 6.25-6.28 TB/s for the round-2 launch (1024-thread blocks, no barrier), which in turn beats 256 + barrier
                 // with the UNSIGNED network (5.93-5.97) -- gpurun_out r03_ab_f64form*.log; D < 64 keeps the 512-thread form
+                // (opt-in: signed_lanes.  The unsigned f64 stream keeps the round-2 launch, 1024-thread blocks without the barrier.)
                 constexpr bool F64_SIGNED = sizeof(T) == 8 && LOG2D >= 6 && WHVI_F64_STREAM_FORM == 2;
-                if (exp_big_blocks || (sizeof(T) == 8 && !F64_SIGNED && WHVI_F64_STREAM_FORM != 1)) WHVI_LAUNCH(POLICY_DPP, false, true, BIG);
+                if (exp_big_blocks || (sizeof(T) == 8 && !(F64_SIGNED && signed_lanes) && WHVI_F64_STREAM_FORM != 1)) WHVI_LAUNCH(POLICY_DPP, false, true, BIG);
                 else if constexpr (F64_SIGNED) {
                     note_launch<T>("fwht_rows_kernel", LOG2D, K, POLICY_DPP, false, true, 256, 1, true);
                     hipLaunchKernelGGL((fwht_rows_kernel<T, LOG2D, K, POLICY_DPP, false, true, 256, 1, true>),
@@ -194,11 +198,17 @@ inline void launch_rows(void *dst, const void *src, int64_t n_chunks, int varian
                                        d, s, n_chunks, n_tiles);
                 }
                 else {
-                    // f32 D = 512 .. 2048: the signed DPP network (+1.7 %, kernels.hpp); everything else unsigned
+                    // f32 D = 512 .. 2048 with signed_lanes: the signed DPP network (+1.7 %, kernels.hpp); everything else unsigned
                     constexpr bool SG = std::is_same<T, float>::value && LOG2D >= 9 && LOG2D <= 11;
-                    note_launch<T>("fwht_rows_kernel", LOG2D, K, POLICY_DPP, false, true, 256, 1, SG);
-                    hipLaunchKernelGGL((fwht_rows_kernel<T, LOG2D, K, POLICY_DPP, false, true, 256, 1, SG>),
-                                       dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, st, d, s, n_chunks, n_tiles);
+                    if (SG && signed_lanes) {
+                        note_launch<T>("fwht_rows_kernel", LOG2D, K, POLICY_DPP, false, true, 256, 1, SG);
+                        hipLaunchKernelGGL((fwht_rows_kernel<T, LOG2D, K, POLICY_DPP, false, true, 256, 1, SG>),
+                                           dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, st, d, s, n_chunks, n_tiles);
+                    } else {
+                        note_launch<T>("fwht_rows_kernel", LOG2D, K, POLICY_DPP, false, true, 256, 1, false);
+                        hipLaunchKernelGGL((fwht_rows_kernel<T, LOG2D, K, POLICY_DPP, false, true, 256, 1, false>),
+                                           dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, st, d, s, n_chunks, n_tiles);
+                    }
                 }
             } else if (big && sizeof(T) == 8) WHVI_LAUNCH(POLICY_DPP, false, false, BIG);
             // cache-resident sizes: 256-thread blocks match or beat 1024 at every size (tools/probe_midsize.py:
@@ -353,6 +363,7 @@ inline int fwht_dispatch(void *dst, const void *src, int64_t rows, int32_t log2d
     // variant bits 20..22 (whvi_fwht_ex): launch form of rows longer than one wave tile, for cross-checks and A/Bs --
     // LONG_PASSES: the round-1 path (2^LOW-element pieces + high-bit passes) for every long row
     const int long_form = (variant >> 20) & 7;
+    const bool signed_lanes = (variant & WHVI_FWHT_SIGNED_LANES) != 0;
     variant &= 0xFFFFF;
     const bool passes_only = long_form == LONG_PASSES || long_form == LONG_PASSES_UNGROUPED;
     const bool block_rows = log2d > max_single_pass_log2d<T>() && !(passes_only && sizeof(T) != 2);
@@ -413,7 +424,7 @@ inline int fwht_dispatch(void *dst, const void *src, int64_t rows, int32_t log2d
         if constexpr (L <= max_single_pass_log2d<T>()) {                                             \
             if (n_chunks > 0)                                                                        \
                 launch_rows<T, L, pick_k<T, L>(), (TUNABLE && L >= 9 && L <= 12)>(dst, src, n_chunks, \
-                                                                                  variant, st);      \
+                                                                                  variant, st, signed_lanes); \
             if constexpr ((1 << L) < VEC) {                                                          \
                 if (tail_elems > 0) {                                                                \
                     const int64_t first = (n_chunks * VEC) >> L;                                     \
