@@ -161,6 +161,11 @@ inline void launch_wbar_fwd(void *dst, const void *s1, const void *u, const void
         // the mean term computed in the same launch (whvi_wbar_fwd_mean_*): quarter-size tiles, cached stores.  Two tiles
         // live at once: rows of one 128-register tile (f32 D = 8192, f64 D = 4096) are refused by the dispatch
         constexpr int KM = KS < K ? KS : K;
+        // the dispatch admits this form exactly where two 64-register tiles fit (log2d <= multi_pass_low_log2d); tie the two
+        // statements of that rule together, so that a shape the dispatch lets through can never fall out of this branch
+        // with nothing launched and WHVI_OK returned
+        static_assert(tile_vgprs<T, KM>() <= 64 || LOG2D > multi_pass_low_log2d<T>(),
+                      "whvi_wbar_fwd_mean: the dispatch bound and the two-tile register budget disagree");
         if constexpr (tile_vgprs<T, KM>() <= 64) {
             const int64_t tiles_m = (n_chunks + 64 * KM - 1) / (64 * KM);
             note_launch<T>("wbar_fwd_kernel", LOG2D, KM, false, true);

@@ -174,7 +174,13 @@ def evaluate_bayesian_regression_dnn(X, y, device, checkpoint_dir, *, epochs1: i
     The keyword arguments are not in the reference (its values are the defaults): ``epochs1`` / ``epochs2`` /
     ``n_splits`` / ``batch_size`` / ``hidden`` / ``eval_samples`` for smaller runs; ``fast`` -- ``None`` = on a GPU --
     selects ``make_optimizer(capturable=True, packed=True)``, ``train_model(graphed=True)`` and ``DeviceBatches``: the same
-    arithmetic per step (tests/test_config_parity.py::test_evaluation_harness_fast_path_equals_the_reference_flow), the
+    update per step WITHIN A TOLERANCE, not bit for bit -- the fast path keeps the learning rate as a float32 device scalar
+    evaluated with the device's pow() (``DeviceDecayLR``: float64 arithmetic, ONE rounding to float32, <= 1.2e-7 relative
+    to the reference's Python-float LambdaLR rate over 3 000 steps, tests/test_config_parity.py::
+    test_one_launch_schedule_is_the_reference_schedule_gpu) and torch's fused Adam may round intermediate terms
+    differently; the parity test of the two flows covers a handful of steps
+    (tests/test_config_parity.py::test_evaluation_harness_fast_path_equals_the_reference_flow), not the 252 500-step
+    protocol, over which such differences compound like any float32 training noise.  ``fast=False`` is the reference's flow.  The
     308-row yacht data set's 252 500 steps per split in minutes instead of an hour; ``pbar_update_period`` (reference: 1,
     i.e. one device-to-host read of KL and MNLL per epoch; fast path default 500); ``optimizer_kwargs`` for
     ``make_optimizer`` (``lambda0`` enters the rate squared -- the defaults give 1e-6)."""
