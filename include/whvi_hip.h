@@ -278,6 +278,11 @@ int whvi_wbar_bwd_f64(void *grad_u, void *part_s1, void *part_s2, const void *gr
  *   log2d in [2, 12] (f32) / [1, 11] (f64). */
 #define WHVI_DIAG_X_SHARED  1
 #define WHVI_DIAG_MEAN_PLUS 2
+/* Element-wise neighbours fused in (an nn.ReLU in front of / behind the layer in the caller's nn.Sequential, src/networks.py:49
+ * running the reference's module list): x is passed through max(x, 0) on load, resp. the result before the store -- the
+ * values torch.relu gives (NaN stays NaN), one read + one write of the activations instead of three. */
+#define WHVI_DIAG_RELU_IN   4
+#define WHVI_DIAG_RELU_OUT  8
 /* tuning / cross-check (same values either way): force the streaming (non-temporal) or the cached launch instead of the
  * choice by size; keep the plain block order on a shared input */
 #define WHVI_DIAG_TUNE_NT          16
@@ -298,14 +303,17 @@ int whvi_diag_apply_f64(void *out, const void *x, const void *s1, const void *s2
  *   part   : workspace of S * n_slabs * 2 * D elements, n_slabs = whvi_diag_apply_bwd_slabs(dtype, S, B, log2d) -- the
  *            batch reduction sum_b g (.) x runs over n_slabs row slabs per sample, combined in slab order by a second,
  *            tiny launch inside the same call (deterministic summation order; no atomics).
- * Non-finite g propagates element-wise (no attempt to mimic the matrix route on a diverged backward pass). */
+ * Non-finite g propagates element-wise (no attempt to mimic the matrix route on a diverged backward pass).
+ * x is the forward's input as it was passed (BEFORE a fused WHVI_DIAG_RELU_IN); bias (the forward's, or NULL) is read only with
+ * WHVI_DIAG_RELU_OUT, whose mask is recomputed from x, the diagonal and the bias with the forward's roundings (torch's
+ * threshold_backward: the gradient passes unless the activation's result is <= 0). */
 int64_t whvi_diag_apply_bwd_slabs(int32_t dtype, int64_t S, int64_t B, int32_t log2d);
 int whvi_diag_apply_bwd_f32(void *grad_x, void *out, void *part, const void *g, const void *x, const void *s1,
-                            const void *s2, const void *u, int64_t S, int64_t B, int32_t log2d, int64_t n_slabs,
-                            int32_t flags, void *stream);
+                            const void *s2, const void *u, const void *bias, int64_t S, int64_t B, int32_t log2d,
+                            int64_t n_slabs, int32_t flags, void *stream);
 int whvi_diag_apply_bwd_f64(void *grad_x, void *out, void *part, const void *g, const void *x, const void *s1,
-                            const void *s2, const void *u, int64_t S, int64_t B, int32_t log2d, int64_t n_slabs,
-                            int32_t flags, void *stream);
+                            const void *s2, const void *u, const void *bias, int64_t S, int64_t B, int32_t log2d,
+                            int64_t n_slabs, int32_t flags, void *stream);
 
 /* whvi_reparam_kl_f32 with the eps draw inside the kernel: Philox4x32-10 + Box-Muller, one standard
  * normal per (matrix, sample, element), written to eps_out (J, S, D) for the backward pass / inspection.  The

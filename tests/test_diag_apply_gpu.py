@@ -283,3 +283,87 @@ def test_argument_checks(hip_lib):
     bw = _hip.lib().whvi_diag_apply_bwd_f32
     assert bw(None, p, p, p, p, s1.data_ptr(), s2.data_ptr(), u.data_ptr(), 2, 5, 6, 7, 0, None) == -1      # n_slabs > B
     assert "slab" in _hip.last_error()
+
+
+@pytest.mark.parametrize("shared", [False, True])
+@pytest.mark.parametrize("relu_in,relu_out", [(True, False), (False, True), (True, True)])
+@pytest.mark.parametrize("dtype,D,S,B", [(torch.float32, 16, 3, 70), (torch.float32, 512, 4, 130), (torch.float32, 1024, 3, 65),
+                                         (torch.float64, 256, 2, 33)])
+def test_fused_relu_neighbours_equal_separate_passes(dtype, D, S, B, relu_in, relu_out, shared, hip_lib):
+    """WHVI_DIAG_RELU_IN / _OUT: ``relu(layer(relu(x)))`` in the one launch == torch.relu passes around the unfused launch
+    (== around the matrix route), forward values -- non-finite activations included: relu(-inf) = 0 is finite, relu(NaN)
+    = NaN poisons its row -- and every gradient, bit for bit (the masks are recomputed with the forward's roundings)."""
+    s1, s2, u, bias, g = _operands(dtype, D, S, 17 * D + S, 0.6)
+    x = torch.randn((B, D) if shared else (S, B, D), device=DEV, dtype=dtype, generator=g)
+    flat = x.view(-1, D)
+    flat[3, 1], flat[5, 2], flat[7, 0], flat[9, D - 1] = float("-inf"), float("nan"), float("inf"), 0.0
+    pre = torch.relu(x) if relu_in else x
+    want = matrix_route(pre, s1, s2, u, bias)
+    want = torch.relu(want) if relu_out else want
+    got = _hip.diag_apply(x, s1, s2, u, bias, n_samples=S, relu_in=relu_in, relu_out=relu_out)
+    assert same_values(got, want)
+    unfused = _hip.diag_apply(pre, s1, s2, u, bias, n_samples=S)
+    assert same_values(got, torch.relu(unfused) if relu_out else unfused)
+    # gradients (finite data): the fused Function against torch.relu around the unfused Function
+    x = torch.randn((B, D) if shared else (S, B, D), device=DEV, dtype=dtype, generator=g)
+    gout = torch.randn(S, B, D, device=DEV, dtype=dtype, generator=g)
+    for with_bias in (True, False):
+        b = bias if with_bias else None
+        la = [t.clone().requires_grad_(True) for t in (x, s1, s2, u)] + ([bias.clone().requires_grad_(True)] if with_bias else [None])
+        lb = [t.clone().requires_grad_(True) for t in (x, s1, s2, u)] + ([bias.clone().requires_grad_(True)] if with_bias else [None])
+        ya = DiagApplyFunction.apply(*la, S, True, relu_in, relu_out)
+        yb = DiagApplyFunction.apply(torch.relu(lb[0]) if relu_in else lb[0], *lb[1:], S, True)
+        yb = torch.relu(yb) if relu_out else yb
+        assert torch.equal(ya, yb)
+        ga = torch.autograd.grad(ya, [t for t in la if t is not None], gout)
+        gb = torch.autograd.grad(yb, [t for t in lb if t is not None], gout)
+        for name, a, c in zip(("x", "s1", "s2", "u", "bias"), ga, gb):
+            assert torch.equal(a, c), (name, with_bias)
+    if dtype == torch.float64 and not shared:
+        leaves = [t[..., :8].clone().requires_grad_(True) if t.dim() else t for t in (x[:, :5], s1, s2, u, bias)]
+        leaves = [x[:, :5, :8].clone().requires_grad_(True), s1[:8].clone().requires_grad_(True), s2[:8].clone().requires_grad_(True),
+                  u[:, :8].clone().requires_grad_(True), bias[:, :8].clone().requires_grad_(True)]
+        fn = lambda *a: DiagApplyFunction.apply(*a, S, True, relu_in, relu_out)       # noqa: E731
+        assert torch.autograd.gradcheck(fn, leaves, eps=1e-6, atol=1e-7)
+        assert torch.autograd.gradgradcheck(fn, leaves, eps=1e-6, atol=1e-6)
+
+
+def test_network_folds_relu_into_the_square_layer(monkeypatch, hip_lib):
+    """``WHVINetwork.forward_batched``: an nn.ReLU in front of / behind a square WHVI layer on the GPU is folded into that
+    layer's launch (BASELINE config 4's 3 -> D -> D -> 1 network: both of its activations).  Same predictions, loss and
+    gradients as with the activations run as passes of their own; the per-sample loop and the faithful dataflow never fuse."""
+    import torch.nn as nn
+    import whvi_amd.networks as networks
+    from whvi_amd.layers import WHVILinear
+    from whvi_amd.networks import WHVIRegression
+    torch.manual_seed(8)
+    net = WHVIRegression([WHVILinear(3, 64), nn.ReLU(), WHVILinear(64, 64, bias=True), nn.ReLU(), WHVILinear(64, 1)],
+                         train_samples=5, eval_samples=5)
+    with torch.no_grad():
+        for name, p in net.named_parameters():
+            if name.rsplit(".", 1)[-1] in ("s1", "s2"):
+                p.mul_(30.0)
+            if name.endswith("g_mu") or name.endswith("bias"):
+                p.normal_()
+    net = net.to(DEV).train()
+    x, y = torch.randn(40, 3, device=DEV), torch.randn(40, 1, device=DEV)
+    calls = []
+    real = WHVISquarePow2Matrix.forward_mc
+    monkeypatch.setattr(WHVISquarePow2Matrix, "forward_mc",
+                        lambda self, x_, n, relu_in=False, relu_out=False: (calls.append((relu_in, relu_out)), real(self, x_, n, relu_in, relu_out))[1])
+
+    def run():
+        torch.manual_seed(21)
+        net.zero_grad(set_to_none=True)
+        loss = net.loss(x, y, n=400)
+        loss.backward()
+        return loss.detach(), [p.grad.clone() for p in net.parameters()]
+    fused_loss, fused_grads = run()
+    assert (True, True) in calls, calls                                  # the D = 64 square layer took both activations
+    calls.clear()
+    monkeypatch.setattr(networks, "_fuses_relu", lambda module, h: False)
+    plain_loss, plain_grads = run()
+    assert calls and all(c == (False, False) for c in calls), calls
+    assert torch.equal(fused_loss, plain_loss)
+    for (name, _), a, b in zip(net.named_parameters(), fused_grads, plain_grads):
+        assert torch.equal(a, b), name

@@ -10,8 +10,29 @@ import torch.nn as nn
 from whvi_amd.layers import WHVILinear
 from whvi_amd.networks import WHVIRegression
 
-batch = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 dev = torch.device("cuda", 0)
+if len(sys.argv) > 1 and sys.argv[1] == "predict":
+    # tools/profile_config4.py predict [faithful]: the PREDICTIVE pass bench.py times for config 4 (batch 45 730, 16 MC samples,
+    # eval forward), 10 passes -- the kernel-time shares of the shipped route and of the as-written (faithful) one
+    torch.manual_seed(0)
+    net = WHVIRegression([WHVILinear(3, 1024), nn.ReLU(), WHVILinear(1024, 1024), nn.ReLU(), WHVILinear(1024, 1)],
+                         eval_samples=16).to(dev).eval()
+    if len(sys.argv) > 2 and sys.argv[2] == "faithful":
+        net.sequential[2].weight_submodule.faithful_dataflow = True
+    xb = torch.randn(45730, 3, device=dev)
+    with torch.no_grad():
+        for _ in range(3):
+            net(xb)
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(10):
+            net(xb)
+        e.record()
+        torch.cuda.synchronize()
+    print(f"predictive pass, batch 45730 x 16 MC: {s.elapsed_time(e) / 10:.3f} ms ({' '.join(sys.argv[2:]) or 'shipped route'})", flush=True)
+    sys.exit(0)
+batch = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 torch.manual_seed(0)
 net = WHVIRegression([WHVILinear(3, 1024), nn.ReLU(), WHVILinear(1024, 1024), nn.ReLU(), WHVILinear(1024, 1)],
                      train_samples=16, eval_samples=16).to(dev)

@@ -95,7 +95,7 @@ def _declare_f3(lib):
         fn.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, ctypes.c_int32, ctypes.c_int32, vp]
         fn = getattr(lib, "whvi_diag_apply_bwd_" + sfx)
         fn.restype = ctypes.c_int
-        fn.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, ctypes.c_int32, i64, ctypes.c_int32, vp]
+        fn.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, ctypes.c_int32, i64, ctypes.c_int32, vp]
     lib.whvi_stream_copy_probe.restype = ctypes.c_int
     lib.whvi_stream_copy_probe.argtypes = [vp, vp, i64, vp]
     lib.whvi_diag_apply_bwd_slabs.restype = ctypes.c_int64
@@ -460,7 +460,7 @@ def wbar_bwd(grad_w: torch.Tensor, s1: torch.Tensor, u: torch.Tensor, s2: torch.
     return out
 
 
-DIAG_X_SHARED, DIAG_MEAN_PLUS = 1, 2
+DIAG_X_SHARED, DIAG_MEAN_PLUS, DIAG_RELU_IN, DIAG_RELU_OUT = 1, 2, 4, 8
 DIAG_TUNE_NT, DIAG_TUNE_CACHED, DIAG_TUNE_PLAIN_ORDER = 16, 32, 64      # tuning / cross-check flags (include/whvi_hip.h)
 
 
@@ -471,7 +471,7 @@ def diag_apply_supported(dtype: torch.dtype, d: int) -> bool:
     return dtype == torch.float64 and 2 <= d <= 2048 and (d & (d - 1)) == 0
 
 
-def _diag_operands(x, s1, s2, u, n_samples, mean_plus, what):
+def _diag_operands(x, s1, s2, u, n_samples, mean_plus, what, relu_in=False, relu_out=False):
     if x.device.type != "cuda" or x.dtype not in (torch.float32, torch.float64):
         raise RuntimeError(f"{what}: float32 / float64 CUDA tensors only")
     D = x.shape[-1]
@@ -489,16 +489,19 @@ def _diag_operands(x, s1, s2, u, n_samples, mean_plus, what):
         raise RuntimeError(f"{what}: operand shapes do not match x (u must be ({U}, {D}))")
     if not (u.dtype == s1.dtype == s2.dtype == x.dtype):
         raise RuntimeError(f"{what}: operand dtypes do not match x")
-    flags = (DIAG_X_SHARED if shared else 0) | (DIAG_MEAN_PLUS if mean_plus else 0)
+    flags = ((DIAG_X_SHARED if shared else 0) | (DIAG_MEAN_PLUS if mean_plus else 0) | (DIAG_RELU_IN if relu_in else 0) |
+             (DIAG_RELU_OUT if relu_out else 0))
     return S, B, D, shared, flags
 
 
 def diag_apply(x: torch.Tensor, s1: torch.Tensor, s2: torch.Tensor, u: torch.Tensor, bias: torch.Tensor = None, *,
-               n_samples: int, mean_plus: bool = True, out: torch.Tensor = None, tune: int = 0) -> torch.Tensor:
+               n_samples: int, mean_plus: bool = True, out: torch.Tensor = None, tune: int = 0, relu_in: bool = False,
+               relu_out: bool = False) -> torch.Tensor:
     """One launch: ``out[k] = x[(k)] * (wd(u[0]) + wd(u[1 + k])) + bias`` -- ``h @ (w_bar(g_mu) + w_bar(g_sigma eps_k)).T``
     of src/weights.py:87-93 for all MC samples without the matrices; see whvi_diag_apply_f32 in include/whvi_hip.h.
-    ``x``: (S, B, D) or a shared (B, D); ``u``: (1 + S, D), or (S, D) with ``mean_plus=False``; returns (S, B, D)."""
-    S, B, D, shared, flags = _diag_operands(x, s1, s2, u, n_samples, mean_plus, "diag_apply")
+    ``x``: (S, B, D) or a shared (B, D); ``u``: (1 + S, D), or (S, D) with ``mean_plus=False``; returns (S, B, D).
+    ``relu_in`` / ``relu_out``: an ``nn.ReLU`` in front of / behind the layer fused into the launch (WHVI_DIAG_RELU_*)."""
+    S, B, D, shared, flags = _diag_operands(x, s1, s2, u, n_samples, mean_plus, "diag_apply", relu_in, relu_out)
     x, s1, s2, u = _aligned(x), _aligned(s1), _aligned(s2), _aligned(u)
     if bias is not None:
         if bias.numel() != D or bias.dtype != x.dtype:
@@ -517,11 +520,14 @@ def diag_apply(x: torch.Tensor, s1: torch.Tensor, s2: torch.Tensor, u: torch.Ten
 
 
 def diag_apply_bwd(grad_out: torch.Tensor, x: torch.Tensor, s1: torch.Tensor, s2: torch.Tensor, u: torch.Tensor, *,
-                   n_samples: int, mean_plus: bool = True, need_grad_x: bool = True, tune: int = 0):
+                   n_samples: int, mean_plus: bool = True, need_grad_x: bool = True, tune: int = 0, bias: torch.Tensor = None,
+                   relu_in: bool = False, relu_out: bool = False):
     """Backward of ``diag_apply`` in one call: ``(grad_x (S, B, D) or None, out (4, U, D))`` with the rows of ``out`` as
     whvi_diag_apply_bwd_f32 documents them (slot 0 dL/du, 1 / 2 the per-sample shares of dL/ds1 / dL/ds2, 3 of dL/dbias;
     with ``mean_plus`` row 0 is left for the caller's sum over rows 1 ..)."""
-    S, B, D, shared, flags = _diag_operands(x, s1, s2, u, n_samples, mean_plus, "diag_apply_bwd")
+    S, B, D, shared, flags = _diag_operands(x, s1, s2, u, n_samples, mean_plus, "diag_apply_bwd", relu_in, relu_out)
+    if bias is not None:
+        bias = _aligned(bias.reshape(-1))
     if tuple(grad_out.shape) != (S, B, D) or grad_out.dtype != x.dtype:
         raise RuntimeError("diag_apply_bwd: grad_out must be (n_samples, batch, D) of x's dtype")
     grad_out, x, s1, s2, u = _aligned(grad_out), _aligned(x), _aligned(s1), _aligned(s2), _aligned(u)
@@ -538,7 +544,8 @@ def diag_apply_bwd(grad_out: torch.Tensor, x: torch.Tensor, s1: torch.Tensor, s2
     fn = getattr(L, "whvi_diag_apply_bwd_" + _DTYPE_SUFFIX[x.dtype])
     with _OnDevice(x.device):
         rc = fn(None if grad_x is None else grad_x.data_ptr(), out.data_ptr(), part.data_ptr(), grad_out.data_ptr(),
-                x.data_ptr(), s1.data_ptr(), s2.data_ptr(), u.data_ptr(), S, B, log2d, n_slabs, flags | int(tune), _stream(x))
+                x.data_ptr(), s1.data_ptr(), s2.data_ptr(), u.data_ptr(), None if bias is None else bias.data_ptr(), S, B, log2d,
+                n_slabs, flags | int(tune), _stream(x))
     _check(rc, "whvi_diag_apply_bwd")
     return grad_x, out
 

@@ -25,15 +25,15 @@ WHVI_EXPORT int64_t whvi_diag_apply_bwd_slabs(int32_t dtype, int64_t S, int64_t 
 }
 
 WHVI_EXPORT int whvi_diag_apply_bwd_f32(void *grad_x, void *out, void *part, const void *g, const void *x, const void *s1,
-                                        const void *s2, const void *u, int64_t S, int64_t B, int32_t log2d, int64_t n_slabs,
-                                        int32_t flags, void *stream)
+                                        const void *s2, const void *u, const void *bias, int64_t S, int64_t B, int32_t log2d,
+                                        int64_t n_slabs, int32_t flags, void *stream)
 {
-    return whvi::diag_apply_bwd_dispatch<float>(grad_x, out, part, g, x, s1, s2, u, S, B, log2d, n_slabs, flags, stream);
+    return whvi::diag_apply_bwd_dispatch<float>(grad_x, out, part, g, x, s1, s2, u, bias, S, B, log2d, n_slabs, flags, stream);
 }
 
 WHVI_EXPORT int whvi_diag_apply_bwd_f64(void *grad_x, void *out, void *part, const void *g, const void *x, const void *s1,
-                                        const void *s2, const void *u, int64_t S, int64_t B, int32_t log2d, int64_t n_slabs,
-                                        int32_t flags, void *stream)
+                                        const void *s2, const void *u, const void *bias, int64_t S, int64_t B, int32_t log2d,
+                                        int64_t n_slabs, int32_t flags, void *stream)
 {
-    return whvi::diag_apply_bwd_dispatch<double>(grad_x, out, part, g, x, s1, s2, u, S, B, log2d, n_slabs, flags, stream);
+    return whvi::diag_apply_bwd_dispatch<double>(grad_x, out, part, g, x, s1, s2, u, bias, S, B, log2d, n_slabs, flags, stream);
 }

@@ -33,6 +33,11 @@ __device__ __forceinline__ A wbar_diag(A s1, A s2, A u)
     return p;
 }
 
+// torch.relu / its backward as the fused neighbours compute them (clamp_min(0): NaN stays NaN; threshold_backward: the gradient
+// passes unless the activation's RESULT is <= 0, so it also passes where that result is NaN)
+template <typename A> __device__ __forceinline__ A relu_(A v) { return (v > (A)0 || v != v) ? v : (A)0; }
+constexpr uint32_t DIAG_OPT_MEAN = 1u, DIAG_OPT_RELU_IN = 2u, DIAG_OPT_RELU_OUT = 4u;
+
 template <typename T> struct Chunk { typedef typename Elem<T>::acc type __attribute__((ext_vector_type(Elem<T>::VEC))); };
 
 // One 16-byte chunk (VEC columns starting at col) of w_k = w_bar(u_0) + w_bar(u_{first + k}) -- or w_bar(u_k) alone.
@@ -64,7 +69,7 @@ template <typename T, int LOG2D, int K, bool NT, bool XSHARED>
 __global__ void __launch_bounds__(256)
 diag_apply_kernel(u32x4 *__restrict__ dst, const u32x4 *x, const T *__restrict__ s1, const T *__restrict__ s2,
                   const T *__restrict__ u, const T *__restrict__ bias, int64_t n_chunks, int64_t n_tiles, uint32_t n_rows,
-                  FastDiv by_batch, uint32_t mean_plus, uint32_t sample_fastest)
+                  FastDiv by_batch, uint32_t opts, uint32_t sample_fastest)
 {
     using E = Elem<T>;
     using A = typename E::acc;
@@ -72,6 +77,8 @@ diag_apply_kernel(u32x4 *__restrict__ dst, const u32x4 *x, const T *__restrict__
     constexpr int VEC = E::VEC;
     constexpr int LV = ilog2(VEC);
     constexpr int TILE = 64 * K;
+    const uint32_t mean_plus = opts & DIAG_OPT_MEAN;
+    const bool relu_in = (opts & DIAG_OPT_RELU_IN) != 0, relu_out = (opts & DIAG_OPT_RELU_OUT) != 0;
     constexpr int SH = LOG2D - LV;
     constexpr uint32_t CPR = 1u << SH;
     constexpr uint32_t D = 1u << LOG2D;
@@ -162,6 +169,10 @@ diag_apply_kernel(u32x4 *__restrict__ dst, const u32x4 *x, const T *__restrict__
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         E::unpack(raw[k], r[k]);
+        if (relu_in) {                          // the activation in FRONT of this layer, applied on load (nn.ReLU fused in)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) r[k][e] = relu_(r[k][e]);
+        }
 #pragma unroll
         for (int e = 0; e < VEC; ++e) bad |= !__builtin_isfinite(r[k][e]);
     }
@@ -228,6 +239,10 @@ diag_apply_kernel(u32x4 *__restrict__ dst, const u32x4 *x, const T *__restrict__
 #pragma unroll
             for (int e = 0; e < VEC; ++e) r[k][e] = r[k][e] + bv[e];      // `out + self.bias`, src/weights.py:101-102
         }
+        if (relu_out) {                         // the activation BEHIND this layer, applied before the store
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) r[k][e] = relu_(r[k][e]);
+        }
     }
     if constexpr (NT) __syncthreads();          // the block's 4 waves write their 64 KiB back together
     if (NT && full) {
@@ -264,9 +279,11 @@ template <typename T, int LOG2D> struct DiagBwdGeom {
 template <typename T, int LOG2D, bool NT, bool XSHARED, bool WANT_GX>
 __global__ void __launch_bounds__(256)
 diag_apply_bwd_kernel(u32x4 *__restrict__ gx, T *__restrict__ part, const u32x4 *__restrict__ g, const u32x4 *__restrict__ x,
-                      const T *__restrict__ s1, const T *__restrict__ s2, const T *__restrict__ u, uint32_t B,
-                      uint32_t slab_rows, uint32_t mean_plus)
+                      const T *__restrict__ s1, const T *__restrict__ s2, const T *__restrict__ u, const T *__restrict__ bias,
+                      uint32_t B, uint32_t slab_rows, uint32_t opts)
 {
+    const uint32_t mean_plus = opts & DIAG_OPT_MEAN;
+    const bool relu_in = (opts & DIAG_OPT_RELU_IN) != 0, relu_out = (opts & DIAG_OPT_RELU_OUT) != 0;
     using E = Elem<T>;
     using A = typename E::acc;
     using G = DiagBwdGeom<T, LOG2D>;
@@ -277,10 +294,19 @@ diag_apply_bwd_kernel(u32x4 *__restrict__ gx, T *__restrict__ part, const u32x4 
     const uint32_t b1 = b0 + slab_rows < B ? b0 + slab_rows : B;
     const uint32_t tcol = threadIdx.x & (TPR - 1), rg = threadIdx.x / TPR;
 
-    A w[CPT][VEC];
-    if constexpr (WANT_GX) {
+    A w[CPT][VEC], bv[CPT][VEC];
+    if (WANT_GX || relu_out) {
 #pragma unroll
-        for (int c = 0; c < CPT; ++c) diag_w_chunk<T, LOG2D>(s1, s2, u, k, mean_plus, (uint32_t)(c * TPR + tcol) * VEC, w[c]);
+        for (int c = 0; c < CPT; ++c) {
+            diag_w_chunk<T, LOG2D>(s1, s2, u, k, mean_plus, (uint32_t)(c * TPR + tcol) * VEC, w[c]);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) bv[c][e] = (A)0;
+            if (bias != nullptr) {
+                const typename Chunk<T>::type bc = *reinterpret_cast<const typename Chunk<T>::type *>(bias + (c * TPR + tcol) * VEC);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) bv[c][e] = bc[e];
+            }
+        }
     }
     A acc[CPT][VEC], accb[CPT][VEC];
 #pragma unroll
@@ -312,9 +338,21 @@ diag_apply_bwd_kernel(u32x4 *__restrict__ gx, T *__restrict__ part, const u32x4 
             if (row < b1) {
 #pragma unroll
                 for (int c = 0; c < CPT; ++c) {
-                    A gv[VEC], xv[VEC];
+                    A gv[VEC], xv[VEC], xr[VEC];
                     E::unpack(rg_[i][c], gv);
-                    E::unpack(rx_[i][c], xv);
+                    E::unpack(rx_[i][c], xr);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) xv[e] = relu_in ? relu_(xr[e]) : xr[e];
+                    if (relu_out) {
+                        // the fused activation's backward: the forward's pre-activation x * w (+ bias) recomputed with the same
+                        // roundings instead of a second 16-byte read per chunk; gradient passes unless that result is <= 0
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) {
+                            A z = xv[e] * w[c][e];
+                            if (bias != nullptr) z = z + bv[c][e];
+                            if (relu_(z) <= (A)0) gv[e] = (A)0;
+                        }
+                    }
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) {
                         acc[c][e] = acc[c][e] + gv[e] * xv[e];
@@ -323,7 +361,10 @@ diag_apply_bwd_kernel(u32x4 *__restrict__ gx, T *__restrict__ part, const u32x4 
                     if constexpr (WANT_GX) {
                         A o[VEC];
 #pragma unroll
-                        for (int e = 0; e < VEC; ++e) o[e] = gv[e] * w[c][e];
+                        for (int e = 0; e < VEC; ++e) {
+                            o[e] = gv[e] * w[c][e];
+                            if (relu_in && xv[e] <= (A)0) o[e] = (A)0;
+                        }
                         st16<NT>(gxk + (int64_t)row * CPR + c * TPR + tcol, E::pack(o));
                     }
                 }
@@ -408,7 +449,7 @@ inline int diag_apply_dispatch(void *dst, const void *x, const void *s1, const v
     constexpr int LV = ilog2(Elem<T>::VEC);
     g_err[0] = 0;
     if (S < 0 || B < 0) return fail(WHVI_ERR_ARG, "whvi_diag_apply: negative size%s", "");
-    if (flags & ~(WHVI_DIAG_X_SHARED | WHVI_DIAG_MEAN_PLUS | WHVI_DIAG_TUNE_MASK))
+    if (flags & ~(WHVI_DIAG_X_SHARED | WHVI_DIAG_MEAN_PLUS | WHVI_DIAG_RELU_IN | WHVI_DIAG_RELU_OUT | WHVI_DIAG_TUNE_MASK))
         return fail(WHVI_ERR_ARG, "whvi_diag_apply: unknown flags%s 0x%llx", "", flags);
     if (log2d < LV || log2d > diag_max_log2d<T>())
         return fail(WHVI_ERR_SIZE, "whvi_diag_apply: log2(D)%s = %lld is outside the supported range [%lld, ...]", "", log2d, LV);
@@ -426,7 +467,8 @@ inline int diag_apply_dispatch(void *dst, const void *x, const void *s1, const v
             return fail(WHVI_ERR_OVERLAP, "whvi_diag_apply: dst overlaps x%s", "");
     }
     hipStream_t st = (hipStream_t)stream;
-    const uint32_t mean_plus = (flags & WHVI_DIAG_MEAN_PLUS) ? 1u : 0u;
+    const uint32_t mean_plus = ((flags & WHVI_DIAG_MEAN_PLUS) ? DIAG_OPT_MEAN : 0u) | ((flags & WHVI_DIAG_RELU_IN) ? DIAG_OPT_RELU_IN : 0u) |
+                               ((flags & WHVI_DIAG_RELU_OUT) ? DIAG_OPT_RELU_OUT : 0u);       // the kernels' option word
     const FastDiv db = make_fastdiv((uint32_t)B);
 #define WHVI_DIAG(L, NT, SH)                                                                                   \
     do {                                                                                                        \
@@ -463,13 +505,13 @@ inline int diag_apply_dispatch(void *dst, const void *x, const void *s1, const v
 
 template <typename T>
 inline int diag_apply_bwd_dispatch(void *grad_x, void *out, void *part, const void *g, const void *x, const void *s1,
-                                   const void *s2, const void *u, int64_t S, int64_t B, int32_t log2d, int64_t n_slabs,
-                                   int32_t flags, void *stream)
+                                   const void *s2, const void *u, const void *bias, int64_t S, int64_t B, int32_t log2d,
+                                   int64_t n_slabs, int32_t flags, void *stream)
 {
     constexpr int LV = ilog2(Elem<T>::VEC);
     g_err[0] = 0;
     if (S < 0 || B < 0) return fail(WHVI_ERR_ARG, "whvi_diag_apply_bwd: negative size%s", "");
-    if (flags & ~(WHVI_DIAG_X_SHARED | WHVI_DIAG_MEAN_PLUS | WHVI_DIAG_TUNE_MASK))
+    if (flags & ~(WHVI_DIAG_X_SHARED | WHVI_DIAG_MEAN_PLUS | WHVI_DIAG_RELU_IN | WHVI_DIAG_RELU_OUT | WHVI_DIAG_TUNE_MASK))
         return fail(WHVI_ERR_ARG, "whvi_diag_apply_bwd: unknown flags%s 0x%llx", "", flags);
     if (log2d < LV || log2d > diag_max_log2d<T>())
         return fail(WHVI_ERR_SIZE, "whvi_diag_apply_bwd: log2(D)%s = %lld is outside the supported range [%lld, ...]", "", log2d, LV);
@@ -478,10 +520,11 @@ inline int diag_apply_bwd_dispatch(void *grad_x, void *out, void *part, const vo
         return fail(WHVI_ERR_ARG, "whvi_diag_apply_bwd: bad batch / slab count%s (B = %lld, n_slabs = %lld)", "", B, n_slabs);
     if (S * B >= ((int64_t)1 << 32)) return fail(WHVI_ERR_SIZE, "whvi_diag_apply_bwd: rows are indexed with 32 bits%s", "");
     if (!out || !part || !g || !x || !s1 || !s2 || !u) return fail(WHVI_ERR_ARG, "whvi_diag_apply_bwd: null pointer%s", "");
-    if (((uintptr_t)grad_x | (uintptr_t)out | (uintptr_t)part | (uintptr_t)g | (uintptr_t)x | (uintptr_t)s1 | (uintptr_t)s2 | (uintptr_t)u) & 15)
+    if (((uintptr_t)grad_x | (uintptr_t)out | (uintptr_t)part | (uintptr_t)g | (uintptr_t)x | (uintptr_t)s1 | (uintptr_t)s2 | (uintptr_t)u | (uintptr_t)bias) & 15)
         return fail(WHVI_ERR_ALIGN, "whvi_diag_apply_bwd: a pointer%s is not 16-byte aligned", "");
     hipStream_t st = (hipStream_t)stream;
     const uint32_t mean_plus = (flags & WHVI_DIAG_MEAN_PLUS) ? 1u : 0u;
+    const uint32_t opts = mean_plus | ((flags & WHVI_DIAG_RELU_IN) ? DIAG_OPT_RELU_IN : 0u) | ((flags & WHVI_DIAG_RELU_OUT) ? DIAG_OPT_RELU_OUT : 0u);
     const bool shared = (flags & WHVI_DIAG_X_SHARED) != 0;
     const uint32_t slab_rows = (uint32_t)((B + n_slabs - 1) / n_slabs);
     if ((B + slab_rows - 1) / slab_rows != n_slabs)
@@ -491,8 +534,8 @@ inline int diag_apply_bwd_dispatch(void *grad_x, void *out, void *part, const vo
     do {                                                                                                        \
         note_launch<T>("diag_apply_bwd_kernel", L, (bool)NT, (bool)SH, (bool)GX);                               \
         hipLaunchKernelGGL((diag_apply_bwd_kernel<T, L, NT, SH, GX>), grid, dim3(256), 0, st, (u32x4 *)grad_x, (T *)part, \
-                           (const u32x4 *)g, (const u32x4 *)x, (const T *)s1, (const T *)s2, (const T *)u, (uint32_t)B, \
-                           slab_rows, mean_plus);                                                               \
+                           (const u32x4 *)g, (const u32x4 *)x, (const T *)s1, (const T *)s2, (const T *)u, (const T *)bias, \
+                           (uint32_t)B, slab_rows, opts);                                                       \
     } while (0)
 #define WHVI_CASE(L)                                                                                            \
     case L:                                                                                                     \

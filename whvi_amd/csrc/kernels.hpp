@@ -311,7 +311,12 @@ fwht_rows_kernel(u32x4 *dst, const u32x4 *src, int64_t n_chunks, int64_t n_tiles
     constexpr bool WIDE4 = K * VEC * (int)sizeof(A) / 4 > 64 && sizeof(T) == 4;
     constexpr bool AUTO_SINGLE = sizeof(T) == 2 || (WHVI_ALIGN_SINGLE_PASS == -1 && ((sizeof(T) == 8 && LOG2D <= 11) || WIDE4));
     constexpr bool SINGLE_PASS = ALIGN >= 1 && (WHVI_ALIGN_SINGLE_PASS == 1 || (WHVI_ALIGN_SINGLE_PASS < 0 && AUTO_SINGLE));
-    constexpr bool STORE_NOP = SINGLE_PASS && sizeof(T) != 2;          // the loop-less code issues its stores back to back
+    // ... and so does the loop form of the f32 D = 512 .. 2048 streams for the last six of its sixteen stores (runs of
+    // [2, 1 x 8, 6] in the shipped code object, tools/shipped_isa.py): with one issue slot between all of them the UNSIGNED
+    // network streams at 6.42-6.44 TB/s instead of 6.30-6.31 -- what the signed lane stages were adopted for in round 2,
+    // without giving up the sign of zero (profiles/r04/stream_forms_store_spacing_ab.log).  D = 4096: 6.42 either way, unchanged.
+    constexpr bool F32_MID = std::is_same<T, float>::value && LOG2D >= 9 && LOG2D <= 11 && NT && ALIGN >= 1;
+    constexpr bool STORE_NOP = (SINGLE_PASS && sizeof(T) != 2) || F32_MID;   // the loop-less code issues its stores back to back
     extern __shared__ __attribute__((aligned(16))) char whvi_smem[];
     auto transform = [&](A (&r)[K][VEC]) {
         if constexpr (POLICY == POLICY_LDS)

@@ -66,10 +66,19 @@ class WHVILinear(nn.Module, WHVI):
         """One stochastic pass (one draw of the weights)."""
         return self.weight_submodule.forward(x)
 
-    def forward_mc(self, x, n_samples):
+    def fuses_relu(self, x):
+        """True when this layer's batched pass can fold an ``nn.ReLU`` in front of / behind it into its own launch."""
+        fn = getattr(self.weight_submodule, "fuses_relu", None)
+        return bool(fn is not None and fn(x))
+
+    def forward_mc(self, x, n_samples, relu_in=False, relu_out=False):
         """``n_samples`` stochastic passes at once: (batch, n_in) or (n_samples, batch, n_in) ->
-        (n_samples, batch, n_out).  Used by ``WHVINetwork`` instead of its per-sample loop."""
-        out = self.weight_submodule.forward_mc(x, n_samples)
+        (n_samples, batch, n_out).  Used by ``WHVINetwork`` instead of its per-sample loop.  ``relu_in`` / ``relu_out``
+        (``WHVINetwork.forward_batched`` sets them only where ``fuses_relu``): neighbouring activations folded in."""
+        if relu_in or relu_out:
+            out = self.weight_submodule.forward_mc(x, n_samples, relu_in=relu_in, relu_out=relu_out)
+        else:
+            out = self.weight_submodule.forward_mc(x, n_samples)
         # KL of exactly this pass when the fused reparameterisation kernel produced it (GPU), else None.  MOVED, not copied:
         # the tensor carries this pass's autograd graph, and a second reference on the inner module would keep that graph --
         # and the parameters' gradient accumulators, created on whatever stream ran this pass -- alive until the NEXT pass

@@ -96,9 +96,24 @@ class WHVINetwork(nn.Module, WHVI):
         over it.  Same output layout as the loop: ``(batch, out_dim, n_samples)``."""
         h = x
         fused_kl, complete = None, True
-        for module in self.sequential:
+        modules = list(self.sequential)
+        i = 0
+        while i < len(modules):
+            module = modules[i]
+            # an nn.ReLU whose neighbour is a layer that folds activations into its own launch (the square layer's
+            # whvi_diag_apply on the GPU) is not run as a pass of its own: one read + one write of the (S, batch, D)
+            # activations instead of three.  Same values: the kernel applies max(., 0) on load / before the store.
+            relu_in = False
+            if type(module) is nn.ReLU and i + 1 < len(modules) and _fuses_relu(modules[i + 1], h):
+                relu_in, i = True, i + 1
+                module = modules[i]
             if hasattr(module, "forward_mc"):
-                h = module.forward_mc(h, n_samples)
+                relu_out = (i + 1 < len(modules) and type(modules[i + 1]) is nn.ReLU and _fuses_relu(module, h))
+                if relu_in or relu_out:
+                    h = module.forward_mc(h, n_samples, relu_in=relu_in, relu_out=relu_out)
+                    i += 1 if relu_out else 0
+                else:
+                    h = module.forward_mc(h, n_samples)
                 kl = getattr(module, "_mc_kl", None)
                 module._mc_kl = None
                 if kl is None:
@@ -108,6 +123,7 @@ class WHVINetwork(nn.Module, WHVI):
             else:
                 h = module(h)
                 complete = complete and 'kl' not in dir(module)
+            i += 1
         # sum of the layers' KL terms computed inside this very pass (fused kernel, same parameter values,
         # same autograd graph); consumed -- once -- by loss()
         self._pass_kl = fused_kl if complete and torch.is_tensor(fused_kl) else None
@@ -264,6 +280,11 @@ class WHVINetwork(nn.Module, WHVI):
         y_pred = self(X_test)
         test_mnll = self.likelihood.mnll_batch_estimate(y_test, y_pred, n=y_test.size(0))
         return float(loss(y_pred, y_test).detach()), float(test_mnll.detach())
+
+
+def _fuses_relu(module, h):
+    fn = getattr(module, "fuses_relu", None)
+    return bool(fn is not None and hasattr(module, "forward_mc") and h.device.type == "cuda" and fn(h))
 
 
 def _rmse_of_mean(y_pred, y_true):

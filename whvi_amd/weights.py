@@ -133,27 +133,32 @@ class DiagApplyFunction(torch.autograd.Function):
     over the samples; with ``create_graph`` the same expression as differentiable torch ops."""
 
     @staticmethod
-    def forward(ctx, x, s1, s2, u, bias, n_samples, mean_plus):
+    def forward(ctx, x, s1, s2, u, bias, n_samples, mean_plus, relu_in=False, relu_out=False):
         from whvi_amd import _hip
-        ctx.save_for_backward(x, s1, s2, u)
         ctx.n_samples, ctx.mean_plus = int(n_samples), bool(mean_plus)
+        ctx.relu_in, ctx.relu_out = bool(relu_in), bool(relu_out)
         ctx.bias_shape = None if bias is None else tuple(bias.shape)
-        return _hip.diag_apply(x, s1, s2, u, bias, n_samples=n_samples, mean_plus=mean_plus)
+        # (the fused activations' backward needs no saved output: their masks are recomputed from x, the diagonal and the bias)
+        ctx.save_for_backward(x, s1, s2, u, bias if (bias is not None and relu_out) else None)
+        return _hip.diag_apply(x, s1, s2, u, bias, n_samples=n_samples, mean_plus=mean_plus, relu_in=relu_in, relu_out=relu_out)
 
     @staticmethod
-    def _reference_ops(x, s1, s2, u, bias, mean_plus):
+    def _reference_ops(x, s1, s2, u, bias, mean_plus, relu_in=False, relu_out=False):
         """The same expression as differentiable torch ops (finite operands): double backward, shapes the kernel lacks."""
         D = float(s1.shape[0])
         w = s1 * (D * (u * s2))                                   # (U, D): diag(w_bar(u_r)), the reference's roundings
         if mean_plus:
             w = _mean_plus_rest(w, 0)                             # (S, D)
+        if relu_in:
+            x = torch.relu(x)
         out = (x if x.dim() == 3 else x.unsqueeze(0)) * w.unsqueeze(1)
-        return out + bias.reshape(-1) if bias is not None else out
+        out = out + bias.reshape(-1) if bias is not None else out
+        return torch.relu(out) if relu_out else out
 
     @staticmethod
     def backward(ctx, grad_out):
         from whvi_amd import _hip
-        x, s1, s2, u = ctx.saved_tensors
+        x, s1, s2, u, bias = ctx.saved_tensors
         S, mean_plus = ctx.n_samples, ctx.mean_plus
         need = ctx.needs_input_grad
         if torch.is_grad_enabled():
@@ -161,17 +166,27 @@ class DiagApplyFunction(torch.autograd.Function):
             D = float(s1.shape[0])
             w = s1 * (D * (u * s2))
             w_k = _mean_plus_rest(w, 0) if mean_plus else w
+            xa = torch.relu(x) if ctx.relu_in else x
+            x3 = xa if xa.dim() == 3 else xa.unsqueeze(0)
+            if ctx.relu_out:
+                z = x3 * w_k.unsqueeze(1)
+                if bias is not None:
+                    z = z + bias.reshape(-1)
+                grad_out = grad_out * (z > 0).to(grad_out.dtype)
             gx = grad_out * w_k.unsqueeze(1)
+            if ctx.relu_in:
+                gx = gx * (x3 > 0).to(gx.dtype)
             if x.dim() == 2:
                 gx = gx.sum(dim=0)
-            gw = (grad_out * (x if x.dim() == 3 else x.unsqueeze(0))).sum(dim=1)                    # (S, D)
+            gw = (grad_out * x3).sum(dim=1)                                                  # (S, D)
             gw_u = torch.cat((gw.sum(dim=0, keepdim=True), gw), dim=0) if mean_plus else gw      # d w_k / d w_r
             grad_u = gw_u * (s1 * D * s2)
             grad_s1 = (gw_u * (D * (u * s2))).sum(dim=0)
             grad_s2 = (gw_u * (s1 * D * u)).sum(dim=0)
             grad_bias = grad_out.sum(dim=(0, 1)).reshape(ctx.bias_shape) if ctx.bias_shape is not None else None
-            return gx, grad_s1, grad_s2, grad_u, grad_bias, None, None
-        gx, out = _hip.diag_apply_bwd(grad_out, x, s1, s2, u, n_samples=S, mean_plus=mean_plus, need_grad_x=need[0])
+            return gx, grad_s1, grad_s2, grad_u, grad_bias, None, None, None, None
+        gx, out = _hip.diag_apply_bwd(grad_out, x, s1, s2, u, n_samples=S, mean_plus=mean_plus, need_grad_x=need[0],
+                                      bias=bias, relu_in=ctx.relu_in, relu_out=ctx.relu_out)
         if mean_plus:
             # row 0 <- sum of the sample rows: dL/du_mean and the totals of s1 / s2 / bias, one reduction for all four
             torch.sum(out[:, 1:], dim=1, out=out[:, 0])
@@ -181,7 +196,7 @@ class DiagApplyFunction(torch.autograd.Function):
         if gx is not None and x.dim() == 2:
             gx = gx.sum(dim=0)
         grad_bias = tot[2].reshape(ctx.bias_shape) if ctx.bias_shape is not None else None
-        return gx, tot[0], tot[1], grad_u, grad_bias, None, None
+        return gx, tot[0], tot[1], grad_u, grad_bias, None, None, None, None
 
 
 class ReparamKLFunction(torch.autograd.Function):
@@ -417,12 +432,17 @@ class WHVISquarePow2Matrix(nn.Module):
                 return "kernel"
         return "ops" if mode is True else None
 
-    def _diag_kernel(self, x, u, bias, n_samples, mean_plus):
+    def _diag_kernel(self, x, u, bias, n_samples, mean_plus, relu_in=False, relu_out=False):
         """x: (..., D) shared by all samples when ``n_samples`` is None (one sample), else (S, B, D) / (B, D)."""
         if n_samples is None:
             out = DiagApplyFunction.apply(x.reshape(1, -1, self.D), self.s1, self.s2, u, bias, 1, mean_plus)
             return out.view(x.shape)
-        return DiagApplyFunction.apply(x, self.s1, self.s2, u, bias, n_samples, mean_plus)
+        return DiagApplyFunction.apply(x, self.s1, self.s2, u, bias, n_samples, mean_plus, relu_in, relu_out)
+
+    def fuses_relu(self, x):
+        """True when ``forward_mc(x, ..., relu_in=, relu_out=)`` folds the activations into its one launch (the GPU's diagonal
+        route); otherwise they are applied as separate ``torch.relu`` passes -- same values either way."""
+        return self._diag_route(x) == "kernel"
 
     def sample_lrt(self, h, _bias=None):
         """``h @ (w_bar(g_mu) + w_bar(g_sigma * eps)).T`` with one eps per call
@@ -451,19 +471,24 @@ class WHVISquarePow2Matrix(nn.Module):
             return self._diag_kernel(x, g_tilde.unsqueeze(0), self.bias, None, False)
         return F.linear(x, self.sample(), self.bias)
 
-    def forward_mc(self, x, n_samples):
+    def forward_mc(self, x, n_samples, relu_in=False, relu_out=False):
         """``n_samples`` independent forward passes in one go: ``x`` is ``(batch, D)``
         (shared input) or ``(n_samples, batch, D)``; returns ``(n_samples, batch, D)``.  Sample k is
-        what ``forward`` computes with the k-th row of one ``randn(n_samples, D)`` draw: one fused
-        launch builds every sample's weight matrix, one batched GEMM applies them."""
+        what ``forward`` computes with the k-th row of one ``randn(n_samples, D)`` draw: one launch applies every
+        sample's (diagonal) weight on the GPU, or -- faithful dataflow -- one fused launch builds every sample's weight
+        matrix and one batched GEMM applies them.  ``relu_in`` / ``relu_out``: ``relu(layer(relu(x)))`` -- an ``nn.ReLU``
+        in front of / behind this layer in the caller's module list, folded into the launch where ``fuses_relu(x)``."""
         self._mc_kl = None
+        if (relu_in or relu_out) and not self.fuses_relu(x):
+            out = self.forward_mc(torch.relu(x) if relu_in else x, n_samples)
+            return torch.relu(out) if relu_out else out
         # one randn(S, D) draw (or the in-kernel generator), softplus, g_sigma * eps and the KL terms
         u, kl = _draw_and_reparam(self, self.g_mu.unsqueeze(0), self.g_rho.unsqueeze(0), n_samples, self.lambda_)
         u = u.squeeze(0)                                                          # (1 + S, D)
         self._mc_kl = None if kl is None else kl.squeeze(0)   # KL of this pass, for WHVINetwork.loss
         route = self._diag_route(x)
         if route == "kernel":
-            return self._diag_kernel(x, u, self.bias, n_samples, True)           # (S, batch, D), bias included
+            return self._diag_kernel(x, u, self.bias, n_samples, True, relu_in, relu_out)   # (S, batch, D), bias included
         if route == "ops":
             w = _mean_plus_rest(self._w_bar_diagonal(u), 0)                       # (S, D)
             out = (x if x.dim() == 3 else x.unsqueeze(0)) * w.unsqueeze(1)
