@@ -116,7 +116,9 @@ int whvi_fwht_i32 (void *dst, const void *src, int64_t rows, int32_t log2d, void
  *                 4  as 1 with every pass over the whole buffer instead of 128 MiB row groups
  *   bit 23 (WHVI_FWHT_SIGNED_LANES), with bits 0..19 zero: the production launch of whvi_fwht_<dtype>, except that STREAMING
  *                 launches (buffers beyond the 256 MiB Infinity Cache) of f32 rows of D = 512 .. 2048 and f64 rows of
- *                 D = 64 .. 2048 run their lane stages as fused multiply-adds by +/-1 (6.42 vs 6.31 TB/s, +1.7 %).  A zero
+ *                 D = 64 .. 2048 run their lane stages as fused multiply-adds by +/-1 (round 2-3: +1.7 %; since round 4's store
+ *                 spacing the plain network streams as fast, 6.42-6.44 vs 6.43-6.45 TB/s, and this form is a cross-check of
+ *                 the signed network the fused pipelines use).  A zero
  *                 carries no sign through those: a result that is NEGATIVE zero in the reference's arithmetic (element 0 of a
  *                 row of negative zeros) comes back as +0; every other bit is unchanged
  *                 (tests/test_fwht_gpu.py::test_negative_zero_contract_of_both_launch_forms).  Other shapes ignore the bit.

@@ -281,7 +281,7 @@ def test_argument_checks(hip_lib):
     assert fn(p, p, s1.data_ptr(), s2.data_ptr(), u.data_ptr(), None, 2, 5, 13, 0, None) == -2
     assert fn(None, None, None, None, None, None, 0, 5, 6, 0, None) == 0                             # nothing to do
     bw = _hip.lib().whvi_diag_apply_bwd_f32
-    assert bw(None, p, p, p, p, s1.data_ptr(), s2.data_ptr(), u.data_ptr(), 2, 5, 6, 7, 0, None) == -1      # n_slabs > B
+    assert bw(None, p, p, p, p, s1.data_ptr(), s2.data_ptr(), u.data_ptr(), None, 2, 5, 6, 7, 0, None) == -1      # n_slabs > B
     assert "slab" in _hip.last_error()
 
 

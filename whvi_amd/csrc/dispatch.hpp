@@ -179,9 +179,18 @@ inline void launch_rows(void *dst, const void *src, int64_t n_chunks, int varian
                 // fma per lane-stage element instead of a sign fold + an add, one repair multiply at the end): 6.35-6.38 vs
                 // 6.25-6.28 TB/s for the round-2 launch (1024-thread blocks, no barrier), which in turn beats 256 + barrier
                 // with the UNSIGNED network (5.93-5.97) -- gpurun_out r03_ab_f64form*.log; D < 64 keeps the 512-thread form
-                // (opt-in: signed_lanes.  The unsigned f64 stream keeps the round-2 launch, 1024-thread blocks without the barrier.)
+                // Round 4: the UNSIGNED network in the same 256-thread + barrier launch streams at 6.39-6.41 TB/s since its
+                // stores are issued one slot apart (kernels.hpp: SINGLE_PASS / STORE_NOP) -- what the signed form gave
+                // (6.40) -- so the drop-in entry point takes that and keeps the sign of zero; the signed network is opt-in
+                // (signed_lanes), 1024-thread blocks without the barrier (6.03-6.07) only for rows shorter than 64.
+                // profiles/r04/stream_forms_store_spacing_ab.log
                 constexpr bool F64_SIGNED = sizeof(T) == 8 && LOG2D >= 6 && WHVI_F64_STREAM_FORM == 2;
-                if (exp_big_blocks || (sizeof(T) == 8 && !(F64_SIGNED && signed_lanes) && WHVI_F64_STREAM_FORM != 1)) WHVI_LAUNCH(POLICY_DPP, false, true, BIG);
+                if (exp_big_blocks || (sizeof(T) == 8 && (LOG2D < 6 || WHVI_F64_STREAM_FORM == 0))) WHVI_LAUNCH(POLICY_DPP, false, true, BIG);
+                else if (!signed_lanes && sizeof(T) == 8) {
+                    note_launch<T>("fwht_rows_kernel", LOG2D, K, POLICY_DPP, false, true, 256, 1, false);
+                    hipLaunchKernelGGL((fwht_rows_kernel<T, LOG2D, K, POLICY_DPP, false, true, 256, 1, false>),
+                                       dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, st, d, s, n_chunks, n_tiles);
+                }
                 else if constexpr (F64_SIGNED) {
                     note_launch<T>("fwht_rows_kernel", LOG2D, K, POLICY_DPP, false, true, 256, 1, true);
                     hipLaunchKernelGGL((fwht_rows_kernel<T, LOG2D, K, POLICY_DPP, false, true, 256, 1, true>),
