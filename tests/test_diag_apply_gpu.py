@@ -277,7 +277,7 @@ def test_argument_checks(hip_lib):
     p = x.data_ptr()
     assert fn(p, p, s1.data_ptr(), s2.data_ptr(), u.data_ptr(), None, 2, 5, 6, 1, None) == -5        # shared input, in place
     assert fn(p, p + 16, s1.data_ptr(), s2.data_ptr(), u.data_ptr(), None, 2, 4, 6, 0, None) == -5   # partial overlap
-    assert fn(p, p, s1.data_ptr(), s2.data_ptr(), u.data_ptr(), None, 2, 5, 6, 4, None) == -1        # unknown flag
+    assert fn(p, p, s1.data_ptr(), s2.data_ptr(), u.data_ptr(), None, 2, 5, 6, 128, None) == -1      # unknown flag
     assert fn(p, p, s1.data_ptr(), s2.data_ptr(), u.data_ptr(), None, 2, 5, 13, 0, None) == -2
     assert fn(None, None, None, None, None, None, 0, 5, 6, 0, None) == 0                             # nothing to do
     bw = _hip.lib().whvi_diag_apply_bwd_f32
