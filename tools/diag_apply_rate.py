@@ -44,7 +44,7 @@ for D, S, B, shared in shapes:
         ms = timed(lambda: _hip.diag_apply_bwd(gout, x, s1, s2, u, n_samples=S, need_grad_x=need))
         nb = gout.numel() * 4 + x.numel() * 4 + (gout.numel() * 4 if need else 0)
         line += f" | bwd gx={int(need)} {ms*1e3:8.1f} us {nb/ms/1e6:7.0f} GB/s"
-        for name, tune in (("nt", 16), ("cached", 32)):
+        for name, tune in (("nt", 16), ("cached", 32), ("nt plain order+stores", 16 | 64)):
             ms = timed(lambda: _hip.diag_apply_bwd(gout, x, s1, s2, u, n_samples=S, need_grad_x=need, tune=tune))
             line += f" [{name} {ms*1e3:.1f}]"
     if S * D * D * 4 <= (4 << 30):

@@ -36,7 +36,14 @@ __device__ __forceinline__ A wbar_diag(A s1, A s2, A u)
 // torch.relu / its backward as the fused neighbours compute them (clamp_min(0): NaN stays NaN; threshold_backward: the gradient
 // passes unless the activation's RESULT is <= 0, so it also passes where that result is NaN)
 template <typename A> __device__ __forceinline__ A relu_(A v) { return (v > (A)0 || v != v) ? v : (A)0; }
-constexpr uint32_t DIAG_OPT_MEAN = 1u, DIAG_OPT_RELU_IN = 2u, DIAG_OPT_RELU_OUT = 4u;
+constexpr uint32_t DIAG_OPT_MEAN = 1u, DIAG_OPT_RELU_IN = 2u, DIAG_OPT_RELU_OUT = 4u, DIAG_OPT_PLAIN_ORDER = 8u, DIAG_OPT_PLAIN_STORES = 16u;
+
+// streaming store next to streaming loads: write-through + non-temporal (kernels.hpp: the written lines must not displace the
+// reads in L2), as a global store (per-lane addresses)
+__device__ __forceinline__ void st16_stream(u32x4 *p, const u32x4 &v)
+{
+    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(v) : "memory");
+}
 
 template <typename T> struct Chunk { typedef typename Elem<T>::acc type __attribute__((ext_vector_type(Elem<T>::VEC))); };
 
@@ -280,7 +287,7 @@ template <typename T, int LOG2D, bool NT, bool XSHARED, bool WANT_GX>
 __global__ void __launch_bounds__(256)
 diag_apply_bwd_kernel(u32x4 *__restrict__ gx, T *__restrict__ part, const u32x4 *__restrict__ g, const u32x4 *__restrict__ x,
                       const T *__restrict__ s1, const T *__restrict__ s2, const T *__restrict__ u, const T *__restrict__ bias,
-                      uint32_t B, uint32_t slab_rows, uint32_t opts)
+                      uint32_t B, uint32_t slab_rows, uint32_t n_slabs, uint32_t opts)
 {
     const uint32_t mean_plus = opts & DIAG_OPT_MEAN;
     const bool relu_in = (opts & DIAG_OPT_RELU_IN) != 0, relu_out = (opts & DIAG_OPT_RELU_OUT) != 0;
@@ -289,7 +296,11 @@ diag_apply_bwd_kernel(u32x4 *__restrict__ gx, T *__restrict__ part, const u32x4 
     using G = DiagBwdGeom<T, LOG2D>;
     constexpr int VEC = G::VEC, CPR = G::CPR, TPR = G::TPR, CPT = G::CPT, RG = G::RG, UNR = G::UNR;
     constexpr uint32_t D = 1u << LOG2D;
-    const uint32_t k = blockIdx.y, slab = blockIdx.x, n_slabs = gridDim.x;
+    // 1-D grid of S * n_slabs blocks; streams: XCD-contiguous order (blocks that share an XCD walk one contiguous eighth of
+    // the (S, B, D) buffers), a bijection whenever the grid is a multiple of 8
+    uint32_t lin = blockIdx.x;
+    if (NT && (gridDim.x & 7u) == 0u && !(opts & DIAG_OPT_PLAIN_ORDER)) lin = (lin & 7u) * (gridDim.x >> 3) + (lin >> 3);
+    const uint32_t k = lin / n_slabs, slab = lin - k * n_slabs;
     const uint32_t b0 = slab * slab_rows;
     const uint32_t b1 = b0 + slab_rows < B ? b0 + slab_rows : B;
     const uint32_t tcol = threadIdx.x & (TPR - 1), rg = threadIdx.x / TPR;
@@ -365,7 +376,8 @@ diag_apply_bwd_kernel(u32x4 *__restrict__ gx, T *__restrict__ part, const u32x4 
                             o[e] = gv[e] * w[c][e];
                             if (relu_in && xv[e] <= (A)0) o[e] = (A)0;
                         }
-                        st16<NT>(gxk + (int64_t)row * CPR + c * TPR + tcol, E::pack(o));
+                        if (NT && !(opts & DIAG_OPT_PLAIN_STORES)) st16_stream(gxk + (int64_t)row * CPR + c * TPR + tcol, E::pack(o));
+                        else st16<NT>(gxk + (int64_t)row * CPR + c * TPR + tcol, E::pack(o));
                     }
                 }
             }
@@ -524,18 +536,23 @@ inline int diag_apply_bwd_dispatch(void *grad_x, void *out, void *part, const vo
         return fail(WHVI_ERR_ALIGN, "whvi_diag_apply_bwd: a pointer%s is not 16-byte aligned", "");
     hipStream_t st = (hipStream_t)stream;
     const uint32_t mean_plus = (flags & WHVI_DIAG_MEAN_PLUS) ? 1u : 0u;
-    const uint32_t opts = mean_plus | ((flags & WHVI_DIAG_RELU_IN) ? DIAG_OPT_RELU_IN : 0u) | ((flags & WHVI_DIAG_RELU_OUT) ? DIAG_OPT_RELU_OUT : 0u);
+    // XCD-contiguous block order + write-through stores: measured (tools/diag_apply_rate.py, profiles/r04/diag_apply_rates.log)
+    // +6.6 % on config 4's 9 GB (1.58 -> 1.48 ms, 6.06 TB/s) and -3 % on 2-3 GB streams (0.61 -> 0.63 ms): taken from 4 GiB up
+    const bool long_stream = ((S * B) << log2d) * (int64_t)sizeof(T) * (grad_x ? 3 : 2) >= ((int64_t)4 << 30);
+    const uint32_t opts = mean_plus | ((flags & WHVI_DIAG_RELU_IN) ? DIAG_OPT_RELU_IN : 0u) | ((flags & WHVI_DIAG_RELU_OUT) ? DIAG_OPT_RELU_OUT : 0u) |
+                          (((flags & WHVI_DIAG_TUNE_PLAIN_ORDER) || !long_stream) ? (DIAG_OPT_PLAIN_ORDER | DIAG_OPT_PLAIN_STORES) : 0u);
     const bool shared = (flags & WHVI_DIAG_X_SHARED) != 0;
     const uint32_t slab_rows = (uint32_t)((B + n_slabs - 1) / n_slabs);
     if ((B + slab_rows - 1) / slab_rows != n_slabs)
         return fail(WHVI_ERR_ARG, "whvi_diag_apply_bwd: n_slabs%s = %lld is not a slab count of this batch (use whvi_diag_apply_bwd_slabs)", "", n_slabs);
-    const dim3 grid((unsigned)n_slabs, (unsigned)S);
+    if (n_slabs * S >= ((int64_t)1 << 31)) return fail(WHVI_ERR_SIZE, "whvi_diag_apply_bwd: too many blocks%s", "");
+    const dim3 grid((unsigned)(n_slabs * S));
 #define WHVI_DBWD(L, NT, SH, GX)                                                                                \
     do {                                                                                                        \
         note_launch<T>("diag_apply_bwd_kernel", L, (bool)NT, (bool)SH, (bool)GX);                               \
         hipLaunchKernelGGL((diag_apply_bwd_kernel<T, L, NT, SH, GX>), grid, dim3(256), 0, st, (u32x4 *)grad_x, (T *)part, \
                            (const u32x4 *)g, (const u32x4 *)x, (const T *)s1, (const T *)s2, (const T *)u, (const T *)bias, \
-                           (uint32_t)B, slab_rows, opts);                                                       \
+                           (uint32_t)B, slab_rows, (uint32_t)n_slabs, opts);                                    \
     } while (0)
 #define WHVI_CASE(L)                                                                                            \
     case L:                                                                                                     \
