@@ -2,7 +2,7 @@
 # tools/collect_profiles.sh TAG PART -- ON THE GPU BOX: regenerate every rocprofv3 summary kept under profiles/TAG/ from the
 # build in this tree, in one lease per part (PART = 1: headline + configs 3 and 5 with their HBM-traffic records; 2: the
 # round-3 fused instantiations, config 2 / config 4 kernel-time shares, the weight-kernel traces, probe logs and the bench
-# line).  The program is always directly after `--`; counters are collected in passes of their own (one TCC counter per
+# line; 3 (round 4): configs 2 and 4 on the shipped route and on the faithful dataflow, whvi_diag_apply's trace + PMC passes).  The program is always directly after `--`; counters are collected in passes of their own (one TCC counter per
 # pass, MI355X_MICROARCH.md), never together with a trace domain.  Everything lands in gpurun_out/TAG_profiles/ (scratch,
 # merged back by gpurun): copy it to profiles/TAG/ and profiles/hbm_traffic.json.
 #     gpurun --timeout 1200 -- bash tools/collect_profiles.sh r03 1
@@ -39,7 +39,7 @@ if [ "$part" = "1" ]; then
   python3 tools/update_hbm_traffic.py fused_shs_f32_D2048_S64_B8192 "$raw/fused_FETCH_SIZE" "$raw/fused_WRITE_SIZE" "fused_shs_kernel<float, 11" 8589934592 > "$raw/hbm_fused.json"
   python3 tools/update_hbm_traffic.py fwht_f16_D4096_rows1048576 "$raw/f16_FETCH_SIZE" "$raw/f16_WRITE_SIZE" "fwht_rows_kernel<__half, 12" 17179869184 > "$raw/hbm_f16.json"
   cp profiles/hbm_traffic.json "$out/hbm_traffic.json"
-else
+elif [ "$part" = "2" ]; then
   trace fused_inst "$root/tools/profile_fused_inst.py" 30
   pmc fused_inst FETCH_SIZE "$root/tools/profile_fused_inst.py" 4
   pmc fused_inst WRITE_SIZE "$root/tools/profile_fused_inst.py" 4
@@ -61,8 +61,26 @@ else
   python3 tools/probe_fused_inst.py batch-major,sample-major > "$out/fused_instantiations_hip_events.log" 2>&1
   python3 tools/probe_wbar_mean.py > "$out/wbar_mean_one_vs_two_launches.log" 2>&1
   python3 tools/config4_train_step.py 2> /dev/null | tail -1 > "$out/config4_train_step_recipe.json"
-  python3 tools/evaluation_harness_rate.py 2> /dev/null | tail -1 > "$out/uci_protocol_yacht_shape.json"
   python3 tools/probe_wbar_fwd_stream.py > "$out/wbar_fwd_stream_hip_events.log" 2>&1
   python3 bench.py > "$out/bench_N1.json" 2> "$raw/bench_N1.err"
+fi
+if [ "$part" = "3" ]; then
+  # ---- round 4: the shipped route of configs 2 and 4 (whvi_diag_apply) beside the faithful dataflow, and the new kernel's traffic
+  trace config2 "$root/tools/profile_config2.py"
+  trace config2_faithful "$root/tools/profile_config2.py" faithful
+  trace config4_predict "$root/tools/profile_config4.py" predict
+  trace config4_predict_faithful "$root/tools/profile_config4.py" predict faithful
+  trace diag_apply "$root/tools/profile_diag_apply.py" 20
+  pmc diag_apply FETCH_SIZE "$root/tools/profile_diag_apply.py" 4
+  pmc diag_apply WRITE_SIZE "$root/tools/profile_diag_apply.py" 4
+  cd "$root"
+  for n in config2 config2_faithful config4_predict config4_predict_faithful; do
+    python3 tools/filter_stats.py "$(find $raw/${n}_trace -name "*kernel_stats.csv" | head -1)" "$out/${n}_kernel_time_shares.csv"
+    cp "$raw/${n}_trace.log" "$out/${n}_timing.log"
+  done
+  python3 tools/summarize_profile.py "$out/diag_apply_config4_rocprof_summary.csv" 0 "$raw/diag_apply_trace" "$raw/diag_apply_FETCH_SIZE" "$raw/diag_apply_WRITE_SIZE"
+  python3 tools/diag_apply_rate.py > "$out/diag_apply_rates.log" 2>&1
+  python3 tools/stream_forms_r04.py > "$out/stream_forms_final_build.log" 2>&1
+  python3 tools/config4_train_step.py 2> /dev/null | tail -1 > "$out/config4_train_step_recipe.json"
 fi
 ls -la "$out"

@@ -10,6 +10,8 @@ from whvi_amd.layers import WHVILinear
 
 dev = torch.device("cuda", 0)
 layer = WHVILinear(512, 512).to(dev)
+if len(sys.argv) > 1 and sys.argv[1] == "faithful":      # weight construction + GEMM instead of the shipped one-launch route
+    layer.weight_submodule.faithful_dataflow = True
 h = torch.randn(4096, 512, device=dev)
 for phase in ("fwd", "train"):
     for it in range(40):
