@@ -82,7 +82,7 @@ ISSUE_CONTRACTS = [
     ("whvi::wbar_fwd_kernel<float, 9, 16, true, false>", 128, "global_store_dwordx4", "adjacent"),
     ("whvi::diag_apply_kernel<float, 9, 16, true, true>", 128, "global_store_dwordx4", "adjacent"),                    # config 2's layer, shared input
     ("whvi::diag_apply_kernel<float, 10, 16, true, false>", 128, "buffer_store_dwordx4", "spaced"),                     # config 4's middle layer
-    ("whvi::stream_copy_kernel<16, 256>", 128, "buffer_store_dwordx4", "spaced"),                                       # the measured ceiling
+    ("whvi::stream_copy_kernel<float, 16, 256>", 128, "buffer_store_dwordx4", "spaced"),                                       # the measured ceiling
 ]
 
 

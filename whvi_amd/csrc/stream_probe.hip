@@ -9,7 +9,7 @@
 
 namespace whvi {
 
-template <int K, int BLOCK>
+template <typename T, int K, int BLOCK>      // (T only names the launch like the kernels it stands in for: whvi_last_kernel prints <type, ...>)
 __global__ void __launch_bounds__(BLOCK)
 stream_copy_kernel(u32x4 *dst, const u32x4 *src, int64_t n_chunks, int64_t n_tiles)
 {
@@ -71,7 +71,7 @@ int whvi_stream_copy_probe(void *dst, const void *src, int64_t bytes, void *stre
     const int64_t grid = (n_tiles + BLOCK / 64 - 1) / (BLOCK / 64);
     if (grid >= ((int64_t)1 << 31)) return fail(WHVI_ERR_SIZE, "whvi_stream_copy_probe: too large%s", "");
     note_launch<float>("stream_copy_kernel", K, BLOCK);
-    hipLaunchKernelGGL((stream_copy_kernel<K, BLOCK>), dim3((unsigned)grid), dim3(BLOCK), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL((stream_copy_kernel<float, K, BLOCK>), dim3((unsigned)grid), dim3(BLOCK), 0, (hipStream_t)stream,
                        (u32x4 *)dst, (const u32x4 *)src, n_chunks, n_tiles);
     return after_launch("stream_copy_probe");
 }
