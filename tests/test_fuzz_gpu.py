@@ -211,3 +211,43 @@ def test_random_shared_source(case, dtype, log2d, S, B, one, hip_lib):
     else:
         got = _hip.fused_shs(t(x), t(a), t(b), t(c), axis="col", n_samples=S, sample_stride=B, src_shared=True)
     assert np.array_equal(got.cpu().numpy().view(np.uint8), want.view(np.uint8)), (case, dtype, log2d, S, B, one)
+
+
+def _diag_cases():
+    rng = np.random.default_rng(20261005)
+    out = []
+    for i in range(max(12, N_CASES // 2)):
+        dtype = torch.float64 if i % 4 == 3 else torch.float32
+        log2d = int(rng.integers(1 if dtype == torch.float64 else 2, 12 if dtype == torch.float64 else 13))
+        S = int(rng.integers(1, 9))
+        budget = int(rng.choice([1 << 12, 1 << 17, 1 << 21]))
+        B = max(1, int(budget // (S << log2d) * rng.uniform(0.5, 1.5)))
+        out.append((i, dtype, log2d, S, B, bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), bool(rng.integers(0, 2)),
+                    bool(rng.integers(0, 2)), bool(rng.integers(0, 2))))
+    return out
+
+
+@pytest.mark.parametrize("case,dtype,log2d,S,B,shared,mean_plus,relu_in,relu_out,poison", _diag_cases())
+def test_random_diag_apply(case, dtype, log2d, S, B, shared, mean_plus, relu_in, relu_out, poison, hip_lib):
+    """whvi_diag_apply on random shapes / flag combinations (rows shorter and longer than a wave's 64 chunks, ragged batches,
+    blocks straddling samples, partial tiles), with and without non-finite activations, value-identical to the matrix route:
+    weight construction through the butterfly kernels + dense product (src/weights.py:87-93) with torch.relu around it."""
+    from whvi_amd.weights import WBarFunction
+    d = 1 << log2d
+    g = torch.Generator(device=DEV).manual_seed(7000 + case)
+    kw = dict(device=DEV, dtype=dtype, generator=g)
+    s1, s2, bias = torch.randn(d, **kw), torch.randn(d, **kw), torch.randn(1, d, **kw)
+    u = torch.randn(S + (1 if mean_plus else 0), d, **kw)
+    x = torch.randn((B, d) if shared else (S, B, d), **kw)
+    if poison:
+        flat = x.view(-1, d)
+        for r in torch.randint(0, flat.shape[0], (max(1, flat.shape[0] // 7),), device=DEV, generator=g).tolist():
+            flat[r, int(torch.randint(0, d, (1,), device=DEV, generator=g))] = (float("inf"), float("-inf"), float("nan"))[r % 3]
+    use_bias = case % 3 != 0
+    got = _hip.diag_apply(x, s1, s2, u, bias if use_bias else None, n_samples=S, mean_plus=mean_plus, relu_in=relu_in, relu_out=relu_out)
+    W = WBarFunction.apply(s1.unsqueeze(0), u.unsqueeze(0), s2.unsqueeze(0), None, mean_plus).squeeze(0)      # (S, D, D)
+    want = torch.matmul(torch.relu(x) if relu_in else x, W.transpose(1, 2))
+    want = want + bias if use_bias else want
+    want = torch.relu(want) if relu_out else want
+    na, nb = torch.isnan(got), torch.isnan(want)
+    assert got.shape == (S, B, d) and bool((na == nb).all()) and bool((got[~na] == want[~nb]).all()), (case, dtype, log2d, S, B)
