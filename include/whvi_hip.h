@@ -317,6 +317,24 @@ int whvi_diag_apply_bwd_f64(void *grad_x, void *out, void *part, const void *g, 
                             const void *s2, const void *u, const void *bias, int64_t S, int64_t B, int32_t log2d,
                             int64_t n_slabs, int32_t flags, void *stream);
 
+/* The two dense products either side of the square layer in a WHVI regression network, for all Monte-Carlo samples per launch,
+ * as HBM-bound streams (f32; same dataflow as the reference's matrix products -- every product is formed, exact zeros of the
+ * as-written weights included, so non-finite inputs propagate like in the dense product):
+ *   whvi_small_k_apply_f32 : out[s, b, n] = sum_{c < K} x[b, c] * w[s, n, c] (+ bias[n]) (relu with WHVI_APPLY_RELU_OUT)
+ *       `x_padded @ W.T` of WHVIStackedMatrix with a narrow input (src/weights.py:179-180,195-206; WHVILinear(3, 1024): K = 4,
+ *       N = 1024).  x : (B, K) shared by all samples; w : (S, N, K); out : (S, B, N); K = 2^log2k in {4, 8}; N a multiple of 4,
+ *       N * K * 4 + N * 4 bytes <= 64 KiB.  Fused multiply-adds in ascending c.
+ *   whvi_row_dot_f32 : y[s, b] = sum_i x[s, b, i] * w[s, i] (+ bias[0])  (x through max(., 0) first with WHVI_APPLY_RELU_IN)
+ *       `F.linear(x, w[None], bias)` of the transposed WHVIColumnMatrix (src/weights.py:239-251; WHVILinear(1024, 1)).
+ *       x : (S, B, D); w : (S, D); y : (S, B); log2d in [2, 12].  Per-lane partial sums in ascending column order, then a
+ *       butterfly over the wave's lanes: a different summation order than a GEMV's (same tolerance class). */
+#define WHVI_APPLY_RELU_IN  1
+#define WHVI_APPLY_RELU_OUT 2
+int whvi_small_k_apply_f32(void *out, const void *x, const void *w, const void *bias, int64_t S, int64_t B, int64_t N,
+                           int32_t log2k, int32_t flags, void *stream);
+int whvi_row_dot_f32(void *y, const void *x, const void *w, const void *bias, int64_t S, int64_t B, int32_t log2d,
+                     int32_t flags, void *stream);
+
 /* whvi_reparam_kl_f32 with the eps draw inside the kernel: Philox4x32-10 + Box-Muller, one standard
  * normal per (matrix, sample, element), written to eps_out (J, S, D) for the backward pass / inspection.  The
  * generator state is three 64-bit words in DEVICE memory, state = {seed, launch offset, scratch (must be 0)}; the

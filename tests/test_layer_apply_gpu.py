@@ -1,0 +1,124 @@
+"""whvi_small_k_apply_f32 / whvi_row_dot_f32 (whvi_amd/csrc/layer_apply.hpp): the dense products of a stacked layer with a
+narrow input (`x_padded @ W.T`, src/weights.py:179-180,195-206) and of a transposed column layer (`F.linear(x, w)`,
+src/weights.py:239-251) for all Monte-Carlo samples per launch, against the torch.matmul forms they replace -- on arbitrary
+operands, on the layers' as-written (diagonal) weights, with non-finite inputs, and through the Modules with gradients."""
+import numpy as np
+import pytest
+import torch
+
+from whvi_amd import _hip
+from whvi_amd.layers import WHVILinear
+from whvi_amd.weights import WHVIColumnMatrix, WHVIStackedMatrix
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.mark.parametrize("K,N,S,B", [(4, 1024, 16, 333), (4, 16, 3, 1000), (8, 64, 5, 77), (8, 1024, 2, 129), (4, 4, 2, 5),
+                                     (4, 1024, 5, 16384 + 3)])
+def test_small_k_apply_vs_matmul(K, N, S, B, hip_lib):
+    g = torch.Generator(device=DEV).manual_seed(K * N + S)
+    x = torch.randn(B, K, device=DEV, generator=g)
+    w = torch.randn(S, N, K, device=DEV, generator=g)
+    bias = torch.randn(1, N, device=DEV, generator=g)
+    want = torch.matmul(x.double(), w.double().transpose(1, 2)) + bias.double()
+    got = _hip.small_k_apply(x, w, bias)
+    assert _hip.last_kernel().startswith("whvi::small_k_apply_kernel<float, ") and got.shape == (S, B, N)
+    assert float((got.double() - want).abs().max()) <= 2e-6 * float(want.abs().max())
+    assert torch.equal(_hip.small_k_apply(x, w, bias, relu_out=True), torch.relu(got))
+    assert float((_hip.small_k_apply(x, w).double() - (want - bias.double())).abs().max()) <= 2e-6 * float(want.abs().max())
+    # block-diagonal weights (what the stacked layer builds: one non-zero per row of W): the single product, bit for bit,
+    # and a non-finite input poisons its row through the exact zeros like the dense product does
+    wd = torch.zeros_like(w)
+    idx = torch.arange(N, device=DEV)
+    wd[:, idx, idx % K] = w[:, idx, idx % K]
+    x[1, 0], x[2, K - 1], x[3, 1] = float("inf"), float("nan"), float("-inf")
+    got, ref = _hip.small_k_apply(x, wd), torch.matmul(x, wd.transpose(1, 2))
+    na, nb = torch.isnan(got), torch.isnan(ref)
+    assert bool((na == nb).all()) and bool((got[~na] == ref[~nb]).all()) and bool(na[:, 1].all()) and not bool(na[:, 0].any())
+
+
+@pytest.mark.parametrize("D,S,B,relu", [(1024, 16, 257, False), (1024, 3, 90, True), (64, 5, 1000, False), (4, 2, 37, True),
+                                        (4096, 2, 19, False), (512, 4, 40000 + 1, True)])
+def test_row_dot_vs_matmul(D, S, B, relu, hip_lib):
+    g = torch.Generator(device=DEV).manual_seed(D + S + B)
+    x = torch.randn(S, B, D, device=DEV, generator=g)
+    w = torch.randn(S, D, device=DEV, generator=g)
+    bias = torch.randn(1, 1, device=DEV, generator=g)
+    xin = torch.relu(x) if relu else x
+    want = torch.matmul(xin.double(), w.double().unsqueeze(-1)) + bias.double()
+    got = _hip.row_dot(x, w, bias, relu_in=relu)
+    assert _hip.last_kernel().startswith("whvi::row_dot_kernel<float, ") and got.shape == (S, B, 1)
+    scale = float((xin.double().abs() * w.double().abs().unsqueeze(1)).sum(dim=-1).max())       # sum of |terms|: the yardstick
+    assert float((got.double() - want).abs().max()) <= 2e-6 * scale
+    x[0, 1, D // 2], x[S - 1, B - 1, 0] = float("nan"), float("inf")
+    got = _hip.row_dot(x, w)
+    assert bool(torch.isnan(got[0, 1, 0])) and not bool(torch.isfinite(got[S - 1, B - 1, 0])) and bool(torch.isfinite(got[0, 0, 0]))
+
+
+@pytest.mark.parametrize("n_in,n_out,bias", [(3, 64, False), (3, 1024, True), (5, 16, True), (4, 8, False)])
+def test_stacked_layer_batched_pass_with_and_without_the_hip_product(n_in, n_out, bias, hip_lib, monkeypatch):
+    """WHVIStackedMatrix.forward_mc: the HIP product == torch.matmul on the same weights -- value for value (the as-written
+    sub-matrices are diagonal: one non-zero term per sum) -- and so are the gradients to 1e-6."""
+    torch.manual_seed(n_in * 100 + n_out)
+    layer = WHVILinear(n_in, n_out, bias=bias).to(DEV)
+    assert isinstance(layer.weight_submodule, WHVIStackedMatrix)
+    with torch.no_grad():
+        for name, p in layer.named_parameters():
+            p.mul_(20.0) if name.endswith(("s1", "s2")) else p.normal_() if name.endswith(("g_mu", "bias")) else None
+    x = torch.randn(50, n_in, device=DEV, requires_grad=True)
+    outs = {}
+    for flag in (True, False):
+        monkeypatch.setattr(WHVIStackedMatrix, "hip_apply", flag)
+        torch.manual_seed(9)
+        layer.zero_grad(set_to_none=True)
+        x.grad = None
+        y = layer.forward_mc(x, 6)
+        assert ("small_k_apply" in _hip.last_kernel()) == flag
+        (y.square().sum() + layer.kl).backward()
+        outs[flag] = (y.detach(), x.grad.clone(), [p.grad.clone() for p in layer.parameters()])
+    assert outs[True][0].shape == (6, 50, n_out) and torch.equal(outs[True][0], outs[False][0])
+    for a, b in zip([outs[True][1]] + outs[True][2], [outs[False][1]] + outs[False][2]):
+        assert float((a - b).abs().max()) <= 1e-6 * float(b.abs().max()) + 1e-30
+
+
+@pytest.mark.parametrize("n_in,bias", [(1024, False), (64, True), (16, True)])
+def test_transposed_column_layer_batched_pass_with_and_without_the_hip_dot(n_in, bias, hip_lib, monkeypatch):
+    torch.manual_seed(n_in)
+    layer = WHVILinear(n_in, 1, bias=bias).to(DEV)
+    assert isinstance(layer.weight_submodule, WHVIColumnMatrix) and layer.weight_submodule.transposed
+    with torch.no_grad():
+        for name, p in layer.named_parameters():
+            p.mul_(20.0) if name.endswith(("s1", "s2")) else p.normal_() if name.endswith(("g_mu", "bias")) else None
+    x = torch.randn(4, 33, n_in, device=DEV, requires_grad=True)
+    outs = {}
+    for flag in (True, False):
+        monkeypatch.setattr(WHVIColumnMatrix, "hip_apply", flag)
+        torch.manual_seed(3)
+        layer.zero_grad(set_to_none=True)
+        x.grad = None
+        y = layer.forward_mc(x, 4)
+        assert ("row_dot" in _hip.last_kernel()) == flag
+        (y.square().sum() + layer.kl).backward()
+        outs[flag] = (y.detach(), x.grad.clone(), [p.grad.clone() for p in layer.parameters()])
+    assert outs[True][0].shape == (4, 33, 1)
+    for a, b in zip([outs[True][0], outs[True][1]] + outs[True][2], [outs[False][0], outs[False][1]] + outs[False][2]):
+        assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()) + 1e-30
+
+
+def test_argument_checks(hip_lib):
+    x = torch.randn(8, 4, device=DEV)
+    w = torch.randn(2, 16, 4, device=DEV)
+    with pytest.raises(RuntimeError, match="unsupported"):
+        _hip.small_k_apply(torch.randn(8, 3, device=DEV), torch.randn(2, 16, 3, device=DEV))
+    with pytest.raises(RuntimeError, match="unsupported"):
+        _hip.row_dot(torch.randn(2, 8, 48, device=DEV), torch.randn(2, 48, device=DEV))
+    fn = _hip.lib().whvi_small_k_apply_f32
+    out = torch.empty(2, 8, 16, device=DEV)
+    assert fn(out.data_ptr(), x.data_ptr(), w.data_ptr(), None, 2, 8, 16, 4, 0, None) == -2          # K = 16
+    assert fn(out.data_ptr(), x.data_ptr(), w.data_ptr(), None, 2, 8, 18, 2, 0, None) == -1          # N % 4
+    assert fn(out.data_ptr(), x.data_ptr(), w.data_ptr(), None, 2, 8, 16, 2, 7, None) == -1          # unknown flags
+    assert fn(None, None, None, None, 0, 8, 16, 2, 0, None) == 0
+    rd = _hip.lib().whvi_row_dot_f32
+    assert rd(out.data_ptr(), x.data_ptr(), w.data_ptr(), None, 2, 8, 13, 0, None) == -2
+    assert rd(out.data_ptr(), x.data_ptr(), w.data_ptr(), None, 2, 8, 4, 2, None) == -1

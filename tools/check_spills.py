@@ -12,7 +12,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "whvi_amd", "csrc")
 UNITS = ["fwht_f32", "fwht_f64", "fwht_f16", "fwht_bf16", "fwht_i32", "fused_f32", "fused_f64", "wbar_bwd_f32",
-         "wbar_bwd_f64", "wbar_fwd_f32", "wbar_fwd_f64", "train_aux", "abi", "fwht_wide", "diag_apply", "stream_probe"]
+         "wbar_bwd_f64", "wbar_fwd_f32", "wbar_fwd_f64", "train_aux", "abi", "fwht_wide", "diag_apply", "stream_probe", "layer_apply"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden",
          "-Rpass-analysis=kernel-resource-usage", "-c", "-o", "/dev/null"]
 

@@ -96,6 +96,10 @@ def _declare_f3(lib):
         fn = getattr(lib, "whvi_diag_apply_bwd_" + sfx)
         fn.restype = ctypes.c_int
         fn.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, ctypes.c_int32, i64, ctypes.c_int32, vp]
+    lib.whvi_small_k_apply_f32.restype = ctypes.c_int
+    lib.whvi_small_k_apply_f32.argtypes = [vp, vp, vp, vp, i64, i64, i64, ctypes.c_int32, ctypes.c_int32, vp]
+    lib.whvi_row_dot_f32.restype = ctypes.c_int
+    lib.whvi_row_dot_f32.argtypes = [vp, vp, vp, vp, i64, i64, ctypes.c_int32, ctypes.c_int32, vp]
     lib.whvi_stream_copy_probe.restype = ctypes.c_int
     lib.whvi_stream_copy_probe.argtypes = [vp, vp, i64, vp]
     lib.whvi_diag_apply_bwd_slabs.restype = ctypes.c_int64
@@ -548,6 +552,57 @@ def diag_apply_bwd(grad_out: torch.Tensor, x: torch.Tensor, s1: torch.Tensor, s2
                 n_slabs, flags | int(tune), _stream(x))
     _check(rc, "whvi_diag_apply_bwd")
     return grad_x, out
+
+
+APPLY_RELU_IN, APPLY_RELU_OUT = 1, 2
+
+
+def small_k_apply_supported(x: torch.Tensor, n_out: int) -> bool:
+    """Shapes ``whvi_small_k_apply_f32`` covers: a float32 (B, 4) or (B, 8) GPU input, N a multiple of 4 that fits the LDS."""
+    k = x.shape[-1]
+    return (x.device.type == "cuda" and x.dtype == torch.float32 and x.dim() == 2 and k in (4, 8) and n_out % 4 == 0
+            and n_out * (k + 1) * 4 <= 64 * 1024)
+
+
+def small_k_apply(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor = None, relu_out: bool = False) -> torch.Tensor:
+    """One launch: ``out[s] = x @ w[s].T (+ bias)`` for a narrow input shared by all samples -- x (B, K), K in {4, 8};
+    w (S, N, K); out (S, B, N); see whvi_small_k_apply_f32 in include/whvi_hip.h."""
+    S, N, K = w.shape
+    if not small_k_apply_supported(x, N) or w.dtype != torch.float32 or w.device != x.device or x.shape[1] != K:
+        raise RuntimeError("small_k_apply: unsupported operands")
+    x, w = _aligned(x), _aligned(w)
+    if bias is not None:
+        bias = _aligned(bias.reshape(-1))
+        if bias.numel() != N:
+            raise RuntimeError("small_k_apply: bias must hold N elements")
+    B = x.shape[0]
+    out = torch.empty((S, B, N), dtype=torch.float32, device=x.device)
+    with _OnDevice(x.device):
+        rc = lib().whvi_small_k_apply_f32(out.data_ptr(), x.data_ptr(), w.data_ptr(), None if bias is None else bias.data_ptr(),
+                                          S, B, N, K.bit_length() - 1, APPLY_RELU_OUT if relu_out else 0, _stream(x))
+    _check(rc, "whvi_small_k_apply")
+    return out
+
+
+def row_dot_supported(x: torch.Tensor) -> bool:
+    d = x.shape[-1]
+    return x.device.type == "cuda" and x.dtype == torch.float32 and x.dim() == 3 and 4 <= d <= 4096 and (d & (d - 1)) == 0
+
+
+def row_dot(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor = None, relu_in: bool = False) -> torch.Tensor:
+    """One launch: ``y[s, b] = x[s, b, :] . w[s] (+ bias)`` -- x (S, B, D), w (S, D), y (S, B, 1); see whvi_row_dot_f32."""
+    if not row_dot_supported(x) or tuple(w.shape) != (x.shape[0], x.shape[2]) or w.dtype != torch.float32:
+        raise RuntimeError("row_dot: unsupported operands")
+    x, w = _aligned(x), _aligned(w)
+    S, B, D = x.shape
+    y = torch.empty((S, B, 1), dtype=torch.float32, device=x.device)
+    if bias is not None:
+        bias = bias.reshape(-1).contiguous()
+    with _OnDevice(x.device):
+        rc = lib().whvi_row_dot_f32(y.data_ptr(), x.data_ptr(), w.data_ptr(), None if bias is None else bias.data_ptr(), S, B,
+                                    D.bit_length() - 1, APPLY_RELU_IN if relu_in else 0, _stream(x))
+    _check(rc, "whvi_row_dot")
+    return y
 
 
 def reparam_kl_bwd(grad_u, grad_kl, g_mu, g_rho, eps, sigma, lambda_: float):

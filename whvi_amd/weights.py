@@ -30,7 +30,7 @@ from whvi_amd.fwht.python import FWHTFunction as fwht_python
 from whvi_amd.fwht.python import WHT_matmul as wht_matmul
 
 __all__ = ["WHVISquarePow2Matrix", "WHVIStackedMatrix", "WHVIColumnMatrix", "WBarFunction", "ReparamKLFunction",
-           "ReparamKLPhiloxFunction", "DiagApplyFunction"]
+           "ReparamKLPhiloxFunction", "DiagApplyFunction", "SmallKApplyFunction", "RowDotFunction"]
 
 
 class WBarFunction(torch.autograd.Function):
@@ -197,6 +197,46 @@ class DiagApplyFunction(torch.autograd.Function):
             gx = gx.sum(dim=0)
         grad_bias = tot[2].reshape(ctx.bias_shape) if ctx.bias_shape is not None else None
         return gx, tot[0], tot[1], grad_u, grad_bias, None, None, None, None
+
+
+class SmallKApplyFunction(torch.autograd.Function):
+    """``out[s] = x @ W[s].T`` for a narrow input ``x`` (B, K), K in {4, 8}, shared by all samples, ``W`` (S, N, K): the dense
+    product of a stacked layer's batched pass (src/weights.py:179-180,195-206) as ONE write-only launch
+    (``whvi_small_k_apply_f32``) instead of a batched GEMM with K = 4.  Backward: the two matrix products of the product rule
+    as torch ops (``grad_x = sum_s g[s] @ W[s]``, ``grad_W[s] = g[s].T @ x``)."""
+
+    @staticmethod
+    def forward(ctx, x, W, bias=None):
+        from whvi_amd import _hip
+        ctx.save_for_backward(x, W)
+        ctx.bias_shape = None if bias is None else tuple(bias.shape)
+        return _hip.small_k_apply(x, W, bias)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W = ctx.saved_tensors
+        grad_x = torch.matmul(g, W).sum(dim=0) if ctx.needs_input_grad[0] else None
+        grad_W = torch.matmul(g.transpose(1, 2), x) if ctx.needs_input_grad[1] else None
+        grad_bias = g.sum(dim=(0, 1)).reshape(ctx.bias_shape) if (ctx.bias_shape is not None and ctx.needs_input_grad[2]) else None
+        return grad_x, grad_W, grad_bias
+
+
+class RowDotFunction(torch.autograd.Function):
+    """``y[s, b] = x[s, b, :] . w[s]``: ``F.linear(x, w[None])`` of the transposed column layer for all samples
+    (src/weights.py:239-251) as ONE read-only launch (``whvi_row_dot_f32``).  Backward as torch ops."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        from whvi_amd import _hip
+        ctx.save_for_backward(x, w)
+        return _hip.row_dot(x, w)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        grad_x = g * w.unsqueeze(1) if ctx.needs_input_grad[0] else None
+        grad_w = torch.matmul(x.transpose(1, 2), g).squeeze(-1) if ctx.needs_input_grad[1] else None
+        return grad_x, grad_w
 
 
 class ReparamKLFunction(torch.autograd.Function):
@@ -525,6 +565,7 @@ class _PackedSubMatrix(WHVISquarePow2Matrix):
 
 class WHVIStackedMatrix(nn.Module):
     inkernel_rng = False      # see WHVISquarePow2Matrix
+    hip_apply = True          # batched GPU pass: the narrow-input product as one HIP launch (False: torch.matmul / rocBLAS)
 
     def __init__(self, n_in, n_out, lambda_=1e-5, bias=False):
         """Arbitrary (n_out, n_in) matrix as a vertical stack of square power-of-two blocks
@@ -689,9 +730,13 @@ class WHVIStackedMatrix(nn.Module):
         W = W.transpose(0, 1).reshape(S, J * D, D)                                  # (S, stack*D, D)
         x_padded = torch.zeros((*x.size()[:-1], D), device=x.device)
         x_padded[..., :self.n_in] = x
-        out = torch.matmul(x_padded, W.transpose(1, 2))
-        if self.bias is not None:
-            out = out + self.bias
+        from whvi_amd import _hip
+        if self.hip_apply and _hip.small_k_apply_supported(x_padded, J * D):
+            out = SmallKApplyFunction.apply(x_padded, W, self.bias)                 # one write-only launch (K = D_in = 4 or 8), bias included
+        else:
+            out = torch.matmul(x_padded, W.transpose(1, 2))
+            if self.bias is not None:
+                out = out + self.bias
         return out[..., :self.n_out]
 
     def forward(self, x, use_lrt=True):
@@ -710,6 +755,7 @@ class WHVIStackedMatrix(nn.Module):
 
 class WHVIColumnMatrix(nn.Module):
     inkernel_rng = False      # see WHVISquarePow2Matrix
+    hip_apply = True          # batched GPU pass of the transposed layer: the row dot as one HIP launch (False: torch.matmul)
 
     def __init__(self, n_out, lambda_=1e-5, bias=False, transposed=False):
         """Column (n_out, 1) matrix -- or row (1, n) when ``transposed`` -- cut from a square
@@ -751,8 +797,12 @@ class WHVIColumnMatrix(nn.Module):
         else:
             rows0 = torch.stack([sq.w_bar(g)[0] for g in g_tilde])
         w = rows0 if self.D == sq.D else rows0[:, :self.D]               # (S, D)
-        if self.transposed:                       # weight (1, D): out = F.linear(x, w[None]) per sample = x @ w, one batched
-            out = torch.matmul(x, w.unsqueeze(-1))   # GEMV pass over x (a product + a sum pass moved 2.5x the bytes: 1.6 vs 0.62 ms at config 4)
+        if self.transposed:                       # weight (1, D): out = F.linear(x, w[None]) per sample = x @ w: one read of x
+            from whvi_amd import _hip
+            if self.hip_apply and x.dim() == 3 and x.shape[0] == n_samples and _hip.row_dot_supported(x):
+                out = RowDotFunction.apply(x, w.contiguous())            # one read-only launch for all samples
+            else:
+                out = torch.matmul(x, w.unsqueeze(-1))   # batched GEMV (a product + a sum pass moved 2.5x the bytes: 1.6 vs 0.62 ms at config 4)
         else:                                     # weight (D, 1): out = x[..., :1] * w
             out = x * w.unsqueeze(1)
         return out + self.bias if self.bias is not None else out
