@@ -322,8 +322,8 @@ int whvi_diag_apply_bwd_f64(void *grad_x, void *out, void *part, const void *g, 
  * as-written weights included, so non-finite inputs propagate like in the dense product):
  *   whvi_small_k_apply_f32 : out[s, b, n] = sum_{c < K} x[b, c] * w[s, n, c] (+ bias[n]) (relu with WHVI_APPLY_RELU_OUT)
  *       `x_padded @ W.T` of WHVIStackedMatrix with a narrow input (src/weights.py:179-180,195-206; WHVILinear(3, 1024): K = 4,
- *       N = 1024).  x : (B, K) shared by all samples; w : (S, N, K); out : (S, B, N); K = 2^log2k in {4, 8}; N a multiple of 4,
- *       N * K * 4 + N * 4 bytes <= 64 KiB.  Fused multiply-adds in ascending c.
+ *       N = 1024).  x : (B, K) shared by all samples; w : (S, N, K); out : (S, B, N); K = 2^log2k in {4, 8}; N a multiple of 4
+ *       with N / 4 = (a power of two <= 256) x (1 .. 4).  Fused multiply-adds in ascending c.
  *   whvi_row_dot_f32 : y[s, b] = sum_i x[s, b, i] * w[s, i] (+ bias[0])  (x through max(., 0) first with WHVI_APPLY_RELU_IN)
  *       `F.linear(x, w[None], bias)` of the transposed WHVIColumnMatrix (src/weights.py:239-251; WHVILinear(1024, 1)).
  *       x : (S, B, D); w : (S, D); y : (S, B); log2d in [2, 12].  Per-lane partial sums in ascending column order, then a

@@ -15,7 +15,7 @@ DEV = "cuda"
 
 
 @pytest.mark.parametrize("K,N,S,B", [(4, 1024, 16, 333), (4, 16, 3, 1000), (8, 64, 5, 77), (8, 1024, 2, 129), (4, 4, 2, 5),
-                                     (4, 1024, 5, 16384 + 3)])
+                                     (4, 1024, 5, 16384 + 3), (4, 48, 3, 100), (8, 4096, 2, 50), (4, 3 * 1024, 2, 40)])
 def test_small_k_apply_vs_matmul(K, N, S, B, hip_lib):
     g = torch.Generator(device=DEV).manual_seed(K * N + S)
     x = torch.randn(B, K, device=DEV, generator=g)
@@ -35,7 +35,8 @@ def test_small_k_apply_vs_matmul(K, N, S, B, hip_lib):
     x[1, 0], x[2, K - 1], x[3, 1] = float("inf"), float("nan"), float("-inf")
     got, ref = _hip.small_k_apply(x, wd), torch.matmul(x, wd.transpose(1, 2))
     na, nb = torch.isnan(got), torch.isnan(ref)
-    assert bool((na == nb).all()) and bool((got[~na] == ref[~nb]).all()) and bool(na[:, 1].all()) and not bool(na[:, 0].any())
+    assert bool((na == nb).all()) and bool((got[~na] == ref[~nb]).all())
+    assert bool(na[:, 1, 1::K].all()) and bool(torch.isinf(got[:, 1, 0::K]).all()) and not bool(na[:, 0].any())      # x[1, 0] = inf
 
 
 @pytest.mark.parametrize("D,S,B,relu", [(1024, 16, 257, False), (1024, 3, 90, True), (64, 5, 1000, False), (4, 2, 37, True),
@@ -117,6 +118,7 @@ def test_argument_checks(hip_lib):
     out = torch.empty(2, 8, 16, device=DEV)
     assert fn(out.data_ptr(), x.data_ptr(), w.data_ptr(), None, 2, 8, 16, 4, 0, None) == -2          # K = 16
     assert fn(out.data_ptr(), x.data_ptr(), w.data_ptr(), None, 2, 8, 18, 2, 0, None) == -1          # N % 4
+    assert fn(out.data_ptr(), x.data_ptr(), w.data_ptr(), None, 2, 8, 4 * 7 * 5, 2, 0, None) == -2   # 35 column groups: 5 per thread
     assert fn(out.data_ptr(), x.data_ptr(), w.data_ptr(), None, 2, 8, 16, 2, 7, None) == -1          # unknown flags
     assert fn(None, None, None, None, 0, 8, 16, 2, 0, None) == 0
     rd = _hip.lib().whvi_row_dot_f32

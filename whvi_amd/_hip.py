@@ -560,8 +560,12 @@ APPLY_RELU_IN, APPLY_RELU_OUT = 1, 2
 def small_k_apply_supported(x: torch.Tensor, n_out: int) -> bool:
     """Shapes ``whvi_small_k_apply_f32`` covers: a float32 (B, 4) or (B, 8) GPU input, N a multiple of 4 that fits the LDS."""
     k = x.shape[-1]
-    return (x.device.type == "cuda" and x.dtype == torch.float32 and x.dim() == 2 and k in (4, 8) and n_out % 4 == 0
-            and n_out * (k + 1) * 4 <= 64 * 1024)
+    if not (x.device.type == "cuda" and x.dtype == torch.float32 and x.dim() == 2 and k in (4, 8) and n_out >= 4 and n_out % 4 == 0):
+        return False
+    cpr, tpr = n_out // 4, 1
+    while tpr < 256 and cpr % (tpr * 2) == 0:
+        tpr *= 2
+    return cpr // tpr <= 4
 
 
 def small_k_apply(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor = None, relu_out: bool = False) -> torch.Tensor:

@@ -16,85 +16,69 @@
 
 namespace whvi {
 
-template <int LOG2K, bool NT>
+// Column-owner layout: a thread keeps the K-wide weight rows of its 4 * CPT output columns in registers for the whole slab of
+// batch rows it walks (no LDS, no per-chunk index arithmetic); per row it needs x[b, 0:K] -- the same 16 / 32 bytes for every
+// lane of the block (a broadcast load) -- and writes one 16-byte chunk per owned column group.  A block covers TPR = min(256, N/4)
+// column chunks: for N = 1024 one 4 KiB output row per step, slab after slab a contiguous write-only stream.
+template <int LOG2K, int CPT, bool NT>
 __global__ void __launch_bounds__(256)
 small_k_apply_kernel(u32x4 *__restrict__ dst, const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
-                     int64_t n_chunks, int64_t n_tiles, uint32_t n_rows, uint32_t cpr, FastDiv by_cpr, FastDiv by_batch, uint32_t relu_out)
+                     uint32_t B, uint32_t cpr, uint32_t tpr, uint32_t slab_rows, uint32_t n_slabs, uint32_t relu_out)
 {
-    constexpr int KIN = 1 << LOG2K;                 // input features (4 or 8)
-    constexpr int K = 16, TILE = 64 * K;
+    constexpr int KIN = 1 << LOG2K, G = KIN / 4;
     typedef float f4 __attribute__((ext_vector_type(4)));
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int64_t blk = blockIdx.x;
-    if (NT && (gridDim.x & 7) == 0) blk = (blk & 7) * (int64_t)(gridDim.x >> 3) + (blk >> 3);
-    const int64_t t = blk * 4 + wave;
-    const bool active = t < n_tiles;
-    const int64_t tile0 = t * TILE;
-    const bool full = tile0 + TILE <= n_chunks;
-    // the block's first and last output row -> its sample(s); one sample per block: that sample's (N, KIN) weight goes to LDS
-    // transposed to [r][c-group][chunk] so that the lanes of a wave read consecutive 16-byte words
-    const uint32_t brow0 = by_cpr.div((uint32_t)(blk * 4 * TILE));
-    uint32_t brow1 = by_cpr.div((uint32_t)((blk * 4 + 4) * TILE - 1));
-    if (brow1 >= n_rows) brow1 = n_rows - 1;
-    const uint32_t smp0 = by_batch.div(brow0);
-    const bool one_sample = by_batch.div(brow1) == smp0;
-    extern __shared__ __attribute__((aligned(16))) float lds[];        // 4 * (KIN / 4) * cpr f4 words  (+ cpr for the bias)
-    constexpr int G = KIN / 4;                      // 16-byte groups per weight row
-    f4 *lw = reinterpret_cast<f4 *>(lds);
-    f4 *lb = lw + (size_t)4 * G * cpr;
-    if (one_sample) {
-        const f4 *ws = reinterpret_cast<const f4 *>(w) + (size_t)smp0 * cpr * 4 * G;      // rows n = 4 * chunk + r, G words each
-        for (uint32_t i = threadIdx.x; i < cpr * 4 * G; i += 256) {
-            const uint32_t n = i / G, gidx = i - n * G, chunk = n >> 2, r = n & 3;
-            lw[((size_t)r * G + gidx) * cpr + chunk] = ws[i];
+    uint32_t lin = blockIdx.x;
+    if (NT && (gridDim.x & 7u) == 0u) lin = (lin & 7u) * (gridDim.x >> 3) + (lin >> 3);      // XCD-contiguous
+    const uint32_t s = lin / n_slabs, slab = lin - s * n_slabs;
+    const uint32_t b0 = slab * slab_rows, b1 = b0 + slab_rows < B ? b0 + slab_rows : B;
+    const uint32_t tcol = threadIdx.x % tpr, rg = threadIdx.x / tpr, n_rg = 256u / tpr;
+    f4 wr[CPT][4][G], bv[CPT];
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+        const uint32_t chunk = c * tpr + tcol;                       // output columns 4 * chunk .. 4 * chunk + 3
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int gi = 0; gi < G; ++gi)
+                wr[c][r][gi] = reinterpret_cast<const f4 *>(w)[((size_t)s * cpr * 4 + (size_t)chunk * 4 + r) * G + gi];
+        bv[c] = bias != nullptr ? reinterpret_cast<const f4 *>(bias)[chunk] : f4{0.f, 0.f, 0.f, 0.f};
+    }
+    u32x4 *out = dst + (size_t)s * B * cpr;
+    constexpr int UNR = 4;
+    for (uint32_t b = b0 + rg; b < b1; b += n_rg * UNR) {
+        f4 xv[UNR][G];
+#pragma unroll
+        for (int i = 0; i < UNR; ++i) {
+            const uint32_t row = b + i * n_rg < b1 ? b + i * n_rg : b1 - 1;
+#pragma unroll
+            for (int gi = 0; gi < G; ++gi) xv[i][gi] = reinterpret_cast<const f4 *>(x)[(size_t)row * G + gi];
         }
-        for (uint32_t i = threadIdx.x; i < cpr; i += 256)
-            lb[i] = bias != nullptr ? reinterpret_cast<const f4 *>(bias)[i] : f4{0.f, 0.f, 0.f, 0.f};
-        __syncthreads();
-    }
-    if (!active) {
-        if constexpr (NT) __syncthreads();
-        return;
-    }
-    f4 out[K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const uint32_t c = (uint32_t)(tile0 + k * 64 + lane < n_chunks ? tile0 + k * 64 + lane : n_chunks - 1);   // clamp: valid operands, never stored
-        const uint32_t row = by_cpr.div(c), chunk = c - row * cpr;
-        const uint32_t s = by_batch.div(row), b = row - s * by_batch.d;
-        f4 xv[G];
+        for (int i = 0; i < UNR; ++i) {
+            const uint32_t row = b + i * n_rg;
+            if (row < b1) {
 #pragma unroll
-        for (int gidx = 0; gidx < G; ++gidx) xv[gidx] = reinterpret_cast<const f4 *>(x)[(size_t)b * G + gidx];
-        f4 acc;
+                for (int c = 0; c < CPT; ++c) {
+                    f4 acc;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float a = 0.0f;
+                    for (int r = 0; r < 4; ++r) {
+                        float a = xv[i][0][0] * wr[c][r][0][0];
 #pragma unroll
-            for (int gidx = 0; gidx < G; ++gidx) {
-                const f4 wv = one_sample ? lw[((size_t)r * G + gidx) * cpr + chunk]
-                                         : reinterpret_cast<const f4 *>(w)[((size_t)s * cpr * 4 + (size_t)chunk * 4 + r) * G + gidx];
+                        for (int gi = 0; gi < G; ++gi)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) a = (gidx == 0 && e == 0) ? xv[0][0] * wv[0] : __builtin_fmaf(xv[gidx][e], wv[e], a);
+                            for (int e = 0; e < 4; ++e)
+                                if (gi != 0 || e != 0) a = __builtin_fmaf(xv[i][gi][e], wr[c][r][gi][e], a);
+                        acc[r] = a;
+                    }
+                    if (bias != nullptr) acc = acc + bv[c];
+                    if (relu_out) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[e] = (acc[e] > 0.0f || acc[e] != acc[e]) ? acc[e] : 0.0f;
+                    }
+                    st16<NT>(out + (size_t)row * cpr + c * tpr + tcol, __builtin_bit_cast(u32x4, acc));
+                }
             }
-            acc[r] = a;
         }
-        if (bias != nullptr) {
-            const f4 bv = one_sample ? lb[chunk] : reinterpret_cast<const f4 *>(bias)[chunk];
-            acc = acc + bv;
-        }
-        if (relu_out) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] = (acc[e] > 0.0f || acc[e] != acc[e]) ? acc[e] : 0.0f;
-        }
-        out[k] = acc;
-    }
-    if constexpr (NT) __syncthreads();
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const u32x4 v = __builtin_bit_cast(u32x4, out[k]);
-        if (NT && full) st16<true>(dst + tile0 + k * 64 + lane, v);         // write-only stream: back-to-back nt stores (wbar_fwd.hpp)
-        else if (full || tile0 + k * 64 + lane < n_chunks) st16<false>(dst + tile0 + k * 64 + lane, v);
     }
 }
 
@@ -194,28 +178,41 @@ inline int small_k_apply_dispatch(void *out, const void *x, const void *w, const
     if (flags & ~WHVI_APPLY_RELU_OUT) return fail(WHVI_ERR_ARG, "whvi_small_k_apply: unknown flags%s 0x%llx", "", flags);
     const int64_t rows = S * B;
     if (rows == 0 || N == 0) return WHVI_OK;
-    if (rows >= ((int64_t)1 << 32) || rows * (N / 4) >= ((int64_t)1 << 32))
-        return fail(WHVI_ERR_SIZE, "whvi_small_k_apply: output chunks are indexed with 32 bits%s", "");
+    if (rows >= ((int64_t)1 << 32)) return fail(WHVI_ERR_SIZE, "whvi_small_k_apply: rows are indexed with 32 bits%s", "");
     if (!out || !x || !w) return fail(WHVI_ERR_ARG, "whvi_small_k_apply: null pointer%s", "");
     if (((uintptr_t)out | (uintptr_t)x | (uintptr_t)w | (uintptr_t)bias) & 15)
         return fail(WHVI_ERR_ALIGN, "whvi_small_k_apply: a pointer%s is not 16-byte aligned", "");
     const uint32_t cpr = (uint32_t)(N / 4);
-    const size_t smem = ((size_t)4 * ((1 << log2k) / 4) + 1) * cpr * 16;
-    if (smem > 64 * 1024) return fail(WHVI_ERR_SIZE, "whvi_small_k_apply: N%s = %lld does not fit the block's LDS", "", N);
-    const int64_t n_chunks = rows * cpr, n_tiles = (n_chunks + 1023) / 1024;
-    const FastDiv dc = make_fastdiv(cpr), db = make_fastdiv((uint32_t)B);
-    const bool nt = n_chunks * 16 > NT_MIN_BYTES;
-    const dim3 grid((unsigned)((n_tiles + 3) / 4));
+    uint32_t tpr = 1;
+    while (tpr < 256 && tpr * 2 <= cpr && cpr % (tpr * 2) == 0) tpr *= 2;        // largest power of two <= 256 dividing cpr
+    const uint32_t cpt = cpr / tpr;
+    if (cpt > 4) return fail(WHVI_ERR_SIZE, "whvi_small_k_apply: N%s = %lld needs more than 4 column groups per thread", "", N);
+    const int64_t n_rg = 256 / tpr;
+    int64_t n_slabs = (8 * (int64_t)num_cu() + S - 1) / S;
+    const int64_t most = (B + n_rg * 8 - 1) / (n_rg * 8);
+    if (n_slabs > most) n_slabs = most;
+    if (n_slabs < 1) n_slabs = 1;
+    const int64_t slab_rows = (B + n_slabs - 1) / n_slabs;
+    n_slabs = (B + slab_rows - 1) / slab_rows;
+    if (n_slabs * S >= ((int64_t)1 << 31)) return fail(WHVI_ERR_SIZE, "whvi_small_k_apply: too many blocks%s", "");
+    const bool nt = rows * (int64_t)N * 4 > NT_MIN_BYTES;
+    const dim3 grid((unsigned)(n_slabs * S));
     hipStream_t st = (hipStream_t)stream;
-#define WHVI_SK(L, NTV)                                                                                        \
+#define WHVI_SK(L, C, NTV)                                                                                     \
     do {                                                                                                        \
-        note_launch<float>("small_k_apply_kernel", L, (bool)NTV);                                               \
-        hipLaunchKernelGGL((small_k_apply_kernel<L, NTV>), grid, dim3(256), smem, st, (u32x4 *)out, (const float *)x, \
-                           (const float *)w, (const float *)bias, n_chunks, n_tiles, (uint32_t)rows, cpr, dc, db, \
+        note_launch<float>("small_k_apply_kernel", L, C, (bool)NTV);                                            \
+        hipLaunchKernelGGL((small_k_apply_kernel<L, C, NTV>), grid, dim3(256), 0, st, (u32x4 *)out, (const float *)x, \
+                           (const float *)w, (const float *)bias, (uint32_t)B, cpr, tpr, (uint32_t)slab_rows, (uint32_t)n_slabs, \
                            (uint32_t)((flags & WHVI_APPLY_RELU_OUT) ? 1 : 0));                                  \
     } while (0)
-    if (log2k == 2) { if (nt) WHVI_SK(2, true); else WHVI_SK(2, false); }
-    else { if (nt) WHVI_SK(3, true); else WHVI_SK(3, false); }
+#define WHVI_SKC(L, C) do { if (nt) WHVI_SK(L, C, true); else WHVI_SK(L, C, false); } while (0)
+#define WHVI_SKL(L)                                                                                             \
+    do {                                                                                                        \
+        if (cpt == 1) WHVI_SKC(L, 1); else if (cpt == 2) WHVI_SKC(L, 2); else if (cpt == 3) WHVI_SKC(L, 3); else WHVI_SKC(L, 4); \
+    } while (0)
+    if (log2k == 2) WHVI_SKL(2); else WHVI_SKL(3);
+#undef WHVI_SKL
+#undef WHVI_SKC
 #undef WHVI_SK
     return after_launch("small_k_apply");
 }
