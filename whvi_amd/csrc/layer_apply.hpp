@@ -44,7 +44,7 @@ small_k_apply_kernel(u32x4 *__restrict__ dst, const float *__restrict__ x, const
         bv[c] = bias != nullptr ? reinterpret_cast<const f4 *>(bias)[chunk] : f4{0.f, 0.f, 0.f, 0.f};
     }
     u32x4 *out = dst + (size_t)s * B * cpr;
-    constexpr int UNR = 4;
+    constexpr int UNR = WHVI_SMALL_K_UNR;             // rows (= 16-byte stores per owned column group) in flight per thread
     for (uint32_t b = b0 + rg; b < b1; b += n_rg * UNR) {
         f4 xv[UNR][G];
 #pragma unroll
