@@ -14,6 +14,10 @@
 //       the 64 lanes.  Floating-point summation order differs from a GEMV's: same tolerance class as any other BLAS.
 #include "dispatch.hpp"
 
+#ifndef WHVI_SMALL_K_UNR
+#define WHVI_SMALL_K_UNR 4      // rows in flight per thread (4 / 8 / 16 measured: 0.50 / 0.56 / 0.52 ms at config 4 on one box -- within its run-to-run spread)
+#endif
+
 namespace whvi {
 
 // Column-owner layout: a thread keeps the K-wide weight rows of its 4 * CPT output columns in registers for the whole slab of
