@@ -24,7 +24,7 @@ namespace whvi {
 // batch rows it walks (no LDS, no per-chunk index arithmetic); per row it needs x[b, 0:K] -- the same 16 / 32 bytes for every
 // lane of the block (a broadcast load) -- and writes one 16-byte chunk per owned column group.  A block covers TPR = min(256, N/4)
 // column chunks: for N = 1024 one 4 KiB output row per step, slab after slab a contiguous write-only stream.
-template <int LOG2K, int CPT, bool NT>
+template <typename T, int LOG2K, int CPT, bool NT>      // (T = float; named so that whvi_last_kernel prints the real symbol)
 __global__ void __launch_bounds__(256)
 small_k_apply_kernel(u32x4 *__restrict__ dst, const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
                      uint32_t B, uint32_t cpr, uint32_t tpr, uint32_t slab_rows, uint32_t n_slabs, uint32_t relu_out)
@@ -87,7 +87,7 @@ small_k_apply_kernel(u32x4 *__restrict__ dst, const float *__restrict__ x, const
 }
 
 // y[s, b] = sum_i relu?(x[s, b, i]) * w[s, i] (+ bias[0]); rows of one 16-byte chunk up to one 64-register tile (D = 4 .. 4096)
-template <int LOG2D, bool NT>
+template <typename T, int LOG2D, bool NT>
 __global__ void __launch_bounds__(256)
 row_dot_kernel(float *__restrict__ y, const u32x4 *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
                int64_t n_chunks, int64_t n_tiles, uint32_t n_rows, FastDiv by_batch, uint32_t relu_in)
@@ -205,7 +205,7 @@ inline int small_k_apply_dispatch(void *out, const void *x, const void *w, const
 #define WHVI_SK(L, C, NTV)                                                                                     \
     do {                                                                                                        \
         note_launch<float>("small_k_apply_kernel", L, C, (bool)NTV);                                            \
-        hipLaunchKernelGGL((small_k_apply_kernel<L, C, NTV>), grid, dim3(256), 0, st, (u32x4 *)out, (const float *)x, \
+        hipLaunchKernelGGL((small_k_apply_kernel<float, L, C, NTV>), grid, dim3(256), 0, st, (u32x4 *)out, (const float *)x, \
                            (const float *)w, (const float *)bias, (uint32_t)B, cpr, tpr, (uint32_t)slab_rows, (uint32_t)n_slabs, \
                            (uint32_t)((flags & WHVI_APPLY_RELU_OUT) ? 1 : 0));                                  \
     } while (0)
@@ -241,7 +241,7 @@ inline int row_dot_dispatch(void *y, const void *x, const void *w, const void *b
         constexpr int K_ = pick_k<float, L>();                                                                  \
         const int64_t n_chunks = (rows << L) / 4, n_tiles = (n_chunks + 64 * K_ - 1) / (64 * K_);               \
         note_launch<float>("row_dot_kernel", L, (bool)NTV);                                                     \
-        hipLaunchKernelGGL((row_dot_kernel<L, NTV>), dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, st, (float *)y, \
+        hipLaunchKernelGGL((row_dot_kernel<float, L, NTV>), dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, st, (float *)y, \
                            (const u32x4 *)x, (const float *)w, (const float *)bias, n_chunks, n_tiles, (uint32_t)rows, db, relu_in); \
     } while (0)
 #define WHVI_CASE(L)                                                                                            \
