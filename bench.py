@@ -517,6 +517,27 @@ def _extra_diag_apply(device):
     return out
 
 
+def _extra_layer_apply(device):
+    """Config 4's outer layers as their own launches: the stacked 3 -> 1024 layer's narrow-input product (write-only: 16 x 45 730
+    x 1024 floats out of a (45 730, 4) input and (16, 1024, 4) weights) and the column 1024 -> 1 layer's row dot (read-only),
+    beside the rocBLAS calls (torch.matmul) they replace."""
+    from whvi_amd import _hip
+    S, B, N = 16, 45730, 1024
+    x, W = torch.randn(B, 4, device=device), torch.randn(S, N, 4, device=device)
+    h, w = torch.randn(S, B, N, device=device), torch.randn(S, N, device=device)
+    nbytes = S * B * N * 4
+    out = {}
+    ms = event_ms(lambda: _hip.small_k_apply(x, W), iters=20, warm=5, warm_ms=30.0)
+    out["small_k_apply_K4_N1024"] = {"ms": round(ms, 4), "GB_per_s_written": round(nbytes / ms / 1e6, 1), "frac_of_peak": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4),
+                                     "kernel": _hip.last_kernel(),
+                                     "torch_matmul_ms": round(event_ms(lambda: torch.matmul(x, W.transpose(1, 2)), iters=20, warm=5), 4)}
+    ms = event_ms(lambda: _hip.row_dot(h, w), iters=20, warm=5, warm_ms=30.0)
+    out["row_dot_D1024"] = {"ms": round(ms, 4), "GB_per_s_read": round(nbytes / ms / 1e6, 1), "frac_of_peak": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4),
+                            "kernel": _hip.last_kernel(),
+                            "torch_matmul_ms": round(event_ms(lambda: torch.matmul(h, w.unsqueeze(-1)), iters=20, warm=5), 4)}
+    return out
+
+
 def _extra_layer(device):
     """BASELINE config 2: WHVILinear(512, 512) forward + KL, 32 MC samples, batch 4096, fp32."""
     from whvi_amd.layers import WHVILinear
@@ -596,8 +617,9 @@ def _extra_network(device):
     res["config"] = "batch 45730 x 3, 16 MC samples (the per-GPU share of 128 over 8 GPUs), fp32, eval forward"
     res["note"] = ("top level = the shipped route: the 1024 x 1024 middle layer applies its (exactly diagonal) as-written weight "
                    "in one whvi_diag_apply launch (3 GB read + 3 GB written, both nn.ReLU passes folded into it) instead of 16 "
-                   "weight matrices + a 1.5 TFLOP fp32 GEMM (faithful_dataflow); the stacked 3 -> 1024 layer (K = 4 GEMM) and the "
-                   "column 1024 -> 1 layer (one batched GEMV) keep their as-written dataflow")
+                   "weight matrices + a 1.5 TFLOP fp32 GEMM (faithful_dataflow); the stacked 3 -> 1024 layer (K = 4 product: "
+                   "whvi_small_k_apply) and the column 1024 -> 1 layer (row dot: whvi_row_dot) keep their as-written dataflow, one "
+                   "HBM-bound launch each")
     return res
 
 
@@ -682,6 +704,7 @@ def extras(device):
                     ("wbar_fwd", _extra_wbar_fwd),
                     ("wbar_bwd", _extra_wbar_bwd),
                     ("diag_apply", _extra_diag_apply),
+                    ("layer_apply", _extra_layer_apply),
                     ("whvilinear_512_fwd_kl_32mc_b4096", _extra_layer),
                     ("whviregression_3_1024_1024_1_mc16", _extra_network), ("toy_regression", _extra_toy),
                     ("config4_train_step", _extra_config4_train)):

@@ -95,6 +95,8 @@ def _issue_violations(shipped, contracts):
             bad.append(f"{name}: {k['scratch']} B of scratch")
         if k["vgprs"] + k["agprs"] > budget:
             bad.append(f"{name}: {k['vgprs']} + {k['agprs']} registers > {budget} (occupancy budget)")
+        if mnemonic is None:
+            continue
         runs = store_runs(shipped.ops(name), mnemonic)
         if sum(runs) < 8:
             bad.append(f"{name}: no {mnemonic} stream found ({runs})")
