@@ -614,6 +614,15 @@ def _extra_network(device):
     # values, reference state_dict keys kept): without it every pass gathers 1024 tiny leaves
     net.pack_parameters()
     res["batched_packed_parameters_ms"] = round(event_ms(predict, iters=3, warm=1), 3)
+    # ... and replayed from a hipGraph (whvi_amd.graphs.GraphedPredictor: the ~40 launches of the pass in one; fresh eps per replay)
+    try:
+        from whvi_amd.graphs import GraphedPredictor
+        gp = GraphedPredictor(net, xb, 16)
+        res["batched_hipgraph_replay_ms"] = round(event_ms(lambda: gp(xb), iters=5, warm=2), 3)
+        res["values_finite"] = res["values_finite"] and bool(torch.isfinite(gp(xb)).all())
+        del gp
+    except Exception as err:                      # noqa: BLE001
+        res["batched_hipgraph_replay_ms"] = f"failed: {err!r}"
     res["config"] = "batch 45730 x 3, 16 MC samples (the per-GPU share of 128 over 8 GPUs), fp32, eval forward"
     res["note"] = ("top level = the shipped route: the 1024 x 1024 middle layer applies its (exactly diagonal) as-written weight "
                    "in one whvi_diag_apply launch (3 GB read + 3 GB written, both nn.ReLU passes folded into it) instead of 16 "
