@@ -290,7 +290,8 @@ int whvi_wbar_bwd_f64(void *grad_u, void *part_s1, void *part_s2, const void *gr
 #define WHVI_DIAG_TUNE_NT          16
 #define WHVI_DIAG_TUNE_CACHED      32
 #define WHVI_DIAG_TUNE_PLAIN_ORDER 64
-#define WHVI_DIAG_TUNE_MASK        (16 | 32 | 64)
+#define WHVI_DIAG_TUNE_BIG_TILES   128   /* 16 KiB tiles at cache-resident sizes too (default there: quarter-size tiles) */
+#define WHVI_DIAG_TUNE_MASK        (16 | 32 | 64 | 128)
 int whvi_diag_apply_f32(void *out, const void *x, const void *s1, const void *s2, const void *u, const void *bias,
                         int64_t S, int64_t B, int32_t log2d, int32_t flags, void *stream);
 int whvi_diag_apply_f64(void *out, const void *x, const void *s1, const void *s2, const void *u, const void *bias,

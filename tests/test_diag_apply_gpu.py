@@ -88,6 +88,9 @@ def test_value_identical_to_the_matrix_route(dtype, D, S, B, shared, hip_lib):
     # direct weight sampling (src/weights.py:104-108): one w_bar per sample, no mean row
     assert torch.equal(_hip.diag_apply(x, s1, s2, u[1:], bias, n_samples=S, mean_plus=False),
                        matrix_route(x, s1, s2, u[1:], bias, mean_plus=False))
+    # the launch forms a size-based dispatch would not pick here: streaming, and the 16 KiB tiles of streams at a cached size
+    for tune in (_hip.DIAG_TUNE_NT, _hip.DIAG_TUNE_CACHED | 128, _hip.DIAG_TUNE_NT | _hip.DIAG_TUNE_PLAIN_ORDER):
+        assert torch.equal(_hip.diag_apply(x, s1, s2, u, bias, n_samples=S, tune=tune), want), tune
     if not shared:                                                               # in place
         assert torch.equal(_hip.diag_apply(x, s1, s2, u, bias, n_samples=S, out=x), want)
 
@@ -277,7 +280,7 @@ def test_argument_checks(hip_lib):
     p = x.data_ptr()
     assert fn(p, p, s1.data_ptr(), s2.data_ptr(), u.data_ptr(), None, 2, 5, 6, 1, None) == -5        # shared input, in place
     assert fn(p, p + 16, s1.data_ptr(), s2.data_ptr(), u.data_ptr(), None, 2, 4, 6, 0, None) == -5   # partial overlap
-    assert fn(p, p, s1.data_ptr(), s2.data_ptr(), u.data_ptr(), None, 2, 5, 6, 128, None) == -1      # unknown flag
+    assert fn(p, p, s1.data_ptr(), s2.data_ptr(), u.data_ptr(), None, 2, 5, 6, 1024, None) == -1     # unknown flag
     assert fn(p, p, s1.data_ptr(), s2.data_ptr(), u.data_ptr(), None, 2, 5, 13, 0, None) == -2
     assert fn(None, None, None, None, None, None, 0, 5, 6, 0, None) == 0                             # nothing to do
     bw = _hip.lib().whvi_diag_apply_bwd_f32

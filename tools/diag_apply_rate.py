@@ -34,7 +34,7 @@ for D, S, B, shared in shapes:
     k = _hip.last_kernel()
     nbytes = out.numel() * 4 + (0 if shared else x.numel() * 4)
     line = f"D={D} S={S} B={B} shared={int(shared)}: fwd {ms*1e3:8.1f} us {nbytes/ms/1e6:7.0f} GB/s"
-    for name, tune in (("nt", 16), ("cached", 32), ("nt+plain", 16 | 64), ("cached+plain", 32 | 64)):
+    for name, tune in (("nt", 16), ("cached", 32), ("cached big tiles", 32 | 128), ("nt+plain", 16 | 64), ("cached+plain", 32 | 64)):
         if not shared and "plain" in name:
             continue
         ms = timed(lambda: _hip.diag_apply(x, s1, s2, u, bias, n_samples=S, out=out, tune=tune))

@@ -482,9 +482,10 @@ inline int diag_apply_dispatch(void *dst, const void *x, const void *s1, const v
     const uint32_t mean_plus = ((flags & WHVI_DIAG_MEAN_PLUS) ? DIAG_OPT_MEAN : 0u) | ((flags & WHVI_DIAG_RELU_IN) ? DIAG_OPT_RELU_IN : 0u) |
                                ((flags & WHVI_DIAG_RELU_OUT) ? DIAG_OPT_RELU_OUT : 0u);       // the kernels' option word
     const FastDiv db = make_fastdiv((uint32_t)B);
-#define WHVI_DIAG(L, NT, SH)                                                                                   \
+#define WHVI_DIAG(L, NT, SH) WHVI_DIAG_K(L, NT, SH, (pick_k<T, L>()))
+#define WHVI_DIAG_K(L, NT, SH, KK)                                                                              \
     do {                                                                                                        \
-        constexpr int K_ = pick_k<T, L>();                                                                      \
+        constexpr int K_ = KK;                                                                                  \
         const int64_t n_chunks = (rows << L) / Elem<T>::VEC, n_tiles = (n_chunks + 64 * K_ - 1) / (64 * K_);    \
         /* shared input: sample index fastest within an XCD when every sample is a whole number of 8-block groups */ \
         const int64_t blk_chunks = (int64_t)4 * 64 * K_, per_sample = (B << L) / Elem<T>::VEC;                  \
@@ -501,7 +502,14 @@ inline int diag_apply_dispatch(void *dst, const void *x, const void *s1, const v
         if constexpr (L >= LV && L <= diag_max_log2d<T>()) {                                                    \
             const bool nt = (flags & WHVI_DIAG_TUNE_NT) ? true : (flags & WHVI_DIAG_TUNE_CACHED) ? false           \
                             : stream_sized((rows << L) * (int64_t)sizeof(T), dst, shared ? nullptr : x);        \
-            if (shared) { if (nt) WHVI_DIAG(L, true, true); else WHVI_DIAG(L, false, true); }                   \
+            /* cache-resident results, rows of up to 256 chunks (f32 D <= 1024): quarter-size tiles -- four times the waves with a \
+               quarter of the work each, as for the weight kernels (wbar_fwd.hpp): config 2 60 -> 50-53 us, D = 1024 +5 %, D = 64 \
+               +9 %; NOT for one-row tiles of half the size (D = 2048: 34 -> 57 us).  WHVI_DIAG_TUNE_BIG_TILES: A/B */    \
+            constexpr int NEED_ = (L > LV + 6) ? (1 << (L - LV - 6)) : 1;                                       \
+            constexpr int KS_ = 4;                                                                              \
+            const bool small_ = !nt && NEED_ <= KS_ && KS_ < pick_k<T, L>() && !(flags & WHVI_DIAG_TUNE_BIG_TILES); \
+            if (small_) { if (shared) WHVI_DIAG_K(L, false, true, KS_); else WHVI_DIAG_K(L, false, false, KS_); } \
+            else if (shared) { if (nt) WHVI_DIAG(L, true, true); else WHVI_DIAG(L, false, true); }              \
             else { if (nt) WHVI_DIAG(L, true, false); else WHVI_DIAG(L, false, false); }                        \
         }                                                                                                       \
         break;
@@ -511,6 +519,7 @@ inline int diag_apply_dispatch(void *dst, const void *x, const void *s1, const v
     default: break;
     }
 #undef WHVI_CASE
+#undef WHVI_DIAG_K
 #undef WHVI_DIAG
     return after_launch("diag_apply");
 }
