@@ -80,7 +80,8 @@ ISSUE_CONTRACTS = [
     ("whvi::fused_shs_kernel<float, 12, 16, 1, false, true, 256, 0, 1, false, false>", 168, "buffer_store_dwordx4", "spaced"),
     ("whvi::wbar_fwd_kernel<float, 11, 16, true, false>", 128, "global_store_dwordx4", "adjacent"),
     ("whvi::wbar_fwd_kernel<float, 9, 16, true, false>", 128, "global_store_dwordx4", "adjacent"),
-    ("whvi::diag_apply_kernel<float, 9, 16, true, true>", 128, "global_store_dwordx4", "adjacent"),                    # config 2's layer, shared input
+    ("whvi::diag_apply_kernel<float, 9, 4, false, true>", 64, None, None),                                              # config 2's layer (256 MiB: cached launch, quarter tiles, 8 waves per SIMD)
+    ("whvi::diag_apply_kernel<float, 9, 16, true, true>", 128, "global_store_dwordx4", "adjacent"),                    # the same layer beyond the Infinity Cache
     ("whvi::diag_apply_kernel<float, 10, 16, true, false>", 128, "buffer_store_dwordx4", "spaced"),                     # config 4's middle layer
     ("whvi::stream_copy_kernel<float, 16, 256>", 128, "buffer_store_dwordx4", "spaced"),                                       # the measured ceiling
 ]
