@@ -596,9 +596,8 @@ def _extra_network(device):
     def predict():
         with torch.no_grad():
             return net(xb)
-    square = net.sequential[2].weight_submodule
     for route in ("auto", "faithful"):
-        square.faithful_dataflow = route == "faithful"
+        net.set_faithful_dataflow(route == "faithful")
         part = {}
         for mode in ("batched", "loop"):
             net.mc_mode = mode
@@ -608,7 +607,7 @@ def _extra_network(device):
             res.update(part)
         else:
             res["faithful_dataflow"] = part
-    square.faithful_dataflow = False
+    net.set_faithful_dataflow(False)
     net.mc_mode = "batched"
     # the same pass with the stacked layer's 4 x 256 parameter vectors packed into four tensors (net.pack_parameters(): same
     # values, reference state_dict keys kept): without it every pass gathers 1024 tiny leaves

@@ -18,7 +18,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "predict":
     net = WHVIRegression([WHVILinear(3, 1024), nn.ReLU(), WHVILinear(1024, 1024), nn.ReLU(), WHVILinear(1024, 1)],
                          eval_samples=16).to(dev).eval()
     if len(sys.argv) > 2 and sys.argv[2] == "faithful":
-        net.sequential[2].weight_submodule.faithful_dataflow = True
+        net.set_faithful_dataflow(True)
     xb = torch.randn(45730, 3, device=dev)
     with torch.no_grad():
         for _ in range(3):

@@ -60,6 +60,18 @@ class WHVINetwork(nn.Module, WHVI):
                 module.pack_parameters()
         return self
 
+    def set_faithful_dataflow(self, on: bool = True):
+        """``on``: every WHVI layer of the network evaluates the reference's dataflow op for op on the GPU too -- square layers
+        build their (as written, exactly diagonal) weight matrices and multiply with a dense GEMM, stacked and column layers call
+        ``torch.matmul`` -- instead of the shipped one-launch routes (``whvi_diag_apply``, ``whvi_small_k_apply``,
+        ``whvi_row_dot``), which return the same values.  For cross-checks and A/B timings (bench.py prints both)."""
+        for module in self.modules():
+            if hasattr(type(module), "faithful_dataflow"):
+                module.faithful_dataflow = bool(on)
+            if hasattr(type(module), "hip_apply"):
+                module.hip_apply = not on
+        return self
+
     def set_inkernel_rng(self, on: bool = True):
         """Opt in to drawing eps inside the reparameterisation kernel for the batched MC passes on the GPU
         (``whvi_reparam_kl_philox_f32``): one launch less per layer and pass, hipGraph-safe.  The
