@@ -47,11 +47,14 @@ def hip_lib():
 @pytest.fixture(params=["auto", "faithful"])
 def dataflow(request):
     """Run a test on both evaluation routes of the square weight matrix (whvi_amd/weights.py): "auto" = the one-launch
-    diagonal application on the GPU (the shipped default), "faithful" = weight construction through the FWHT kernels + the
-    dense GEMM, the reference's dataflow op for op (src/weights.py:87-93)."""
-    from whvi_amd.weights import WHVISquarePow2Matrix
+    diagonal application on the GPU and the one-launch products of the stacked / column layers (the shipped defaults),
+    "faithful" = weight construction through the FWHT kernels + dense GEMMs everywhere, the reference's dataflow op for op
+    (src/weights.py:87-93,179-180,250-251)."""
+    from whvi_amd.weights import WHVIColumnMatrix, WHVISquarePow2Matrix, WHVIStackedMatrix
     # (not through ``monkeypatch``: several of these tests call monkeypatch.undo() half way to drop a torch.randn replay)
-    before = WHVISquarePow2Matrix.default_exploit_diagonal
-    WHVISquarePow2Matrix.default_exploit_diagonal = "auto" if request.param == "auto" else False
+    before = (WHVISquarePow2Matrix.default_exploit_diagonal, WHVIStackedMatrix.hip_apply, WHVIColumnMatrix.hip_apply)
+    faithful = request.param != "auto"
+    WHVISquarePow2Matrix.default_exploit_diagonal = False if faithful else "auto"
+    WHVIStackedMatrix.hip_apply = WHVIColumnMatrix.hip_apply = not faithful        # torch.matmul instead of the one-launch products
     yield request.param
-    WHVISquarePow2Matrix.default_exploit_diagonal = before
+    WHVISquarePow2Matrix.default_exploit_diagonal, WHVIStackedMatrix.hip_apply, WHVIColumnMatrix.hip_apply = before
