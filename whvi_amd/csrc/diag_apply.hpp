@@ -18,6 +18,10 @@
 // order (rows of a slab in order per thread, row groups through LDS in order, slabs in order in the finishing kernel).
 #include "dispatch.hpp"
 
+#ifndef WHVI_DIAG_BWD_UNR
+#define WHVI_DIAG_BWD_UNR 4
+#endif
+
 namespace whvi {
 
 // diag(w_bar(u))[i], the factor `h @ w_bar(u).T` multiplies h[:, i] by (see the header comment for the NaN rule)
@@ -226,9 +230,13 @@ diag_apply_kernel(u32x4 *__restrict__ dst, const u32x4 *x, const T *__restrict__
         A wv[VEC], bv[VEC];
         if (one_sample) {
             const chunk_t wc = *reinterpret_cast<const chunk_t *>(lds_w + chunk_col(k) * VEC);
-            const chunk_t bc = *reinterpret_cast<const chunk_t *>(lds_b + chunk_col(k) * VEC);
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) { wv[e] = wc[e]; bv[e] = bc[e]; }
+            for (int e = 0; e < VEC; ++e) { wv[e] = wc[e]; bv[e] = (A)0; }
+            if (bias != nullptr) {                                 // (no bias: no second LDS read per chunk)
+                const chunk_t bc = *reinterpret_cast<const chunk_t *>(lds_b + chunk_col(k) * VEC);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) bv[e] = bc[e];
+            }
         } else {
             const uint32_t row = chunk_row(k) < n_rows ? chunk_row(k) : n_rows - 1;      // rows past the end: valid operands, never stored
             diag_w_chunk<T, LOG2D>(s1, s2, u, by_batch.div(row), mean_plus, chunk_col(k) * VEC, wv);
@@ -280,7 +288,7 @@ template <typename T, int LOG2D> struct DiagBwdGeom {
     static constexpr int TPR = CPR < 256 ? CPR : 256;
     static constexpr int CPT = CPR / TPR;
     static constexpr int RG = 256 / TPR;
-    static constexpr int UNR = CPT >= 4 ? 2 : 4;
+    static constexpr int UNR = CPT >= 4 ? 2 : (CPT == 1 ? WHVI_DIAG_BWD_UNR : 4);      // rows in flight per thread
 };
 
 template <typename T, int LOG2D, bool NT, bool XSHARED, bool WANT_GX>
