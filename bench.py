@@ -513,6 +513,9 @@ def _extra_diag_apply(device):
         out[key] = {"fwd_ms": round(ms, 4), "fwd_GB_per_s": round(nbytes / ms / 1e6, 1), "fwd_frac_of_peak": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4),
                     "bwd_ms": round(ms_b, 4), "bwd_GB_per_s": round(nb / ms_b / 1e6, 1), "bwd_frac_of_peak": round(nb / ms_b / 1e6 / HBM_PEAK_GBS, 4),
                     "bwd_kernel": _hip.last_kernel(), "kernel": kernel, "values_finite": _finite(res)}
+        if max(nbytes, nb) <= 320 << 20:
+            out[key]["note"] = ("working set of about the 256 MiB Infinity Cache: part of it is served from there, so a rate can "
+                                "exceed the HBM peak -- a cache rate, not an HBM fraction")
         del x, res, g
     return out
 
