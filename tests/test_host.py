@@ -536,3 +536,56 @@ def test_evaluation_harness_protocol_on_the_host(tmp_path, capsys):
     with pytest.raises(ValueError):
         DeviceBatches(Xt, yt[:-1])
     assert torch.equal(Cosine()(Xt), torch.cos(Xt))
+
+
+@pytest.mark.parametrize("D", [8, 64])
+def test_diagonal_route_as_torch_ops_on_the_host(D, monkeypatch):
+    """The square layer's route switch on HOST tensors: "auto" (the default) keeps the reference's dataflow there, ``True``
+    applies the diagonal as torch ops (``DiagApplyFunction._reference_ops`` is the same expression), ``faithful_dataflow``
+    round-trips.  The two agree to the dense-H path's rounding noise (src/weights.py:38-39 leaves ~1e-7 off-diagonals), for
+    forward / forward_mc / direct sampling and every gradient; the closed-form backward of DiagApplyFunction (used with
+    create_graph on the GPU) equals autograd through the same expression."""
+    from whvi_amd.weights import DiagApplyFunction, WHVISquarePow2Matrix
+    torch.manual_seed(D)
+    sq = WHVISquarePow2Matrix(D, bias=True)
+    with torch.no_grad():
+        sq.s1.mul_(30.0), sq.s2.mul_(30.0), sq.g_mu.normal_(), sq.bias.normal_()
+    assert sq._diag_mode() == "auto" and sq._diag_route(torch.zeros(2, D)) is None and not sq.faithful_dataflow
+    x = torch.randn(9, D, requires_grad=True)
+    results = {}
+    for mode in (False, True):
+        sq.exploit_diagonal = mode
+        assert sq.faithful_dataflow == (mode is False) and sq._diag_route(x) == ("ops" if mode else None)
+        outs = []
+        for fn in (lambda: sq(x), lambda: sq.forward_mc(x, 3), lambda: sq.forward_mc(x, 3, relu_in=True, relu_out=True)):
+            torch.manual_seed(1)
+            sq.zero_grad(set_to_none=True)
+            x.grad = None
+            y = fn()
+            (y.square().sum() + sq.kl).backward()
+            outs.append([y.detach(), x.grad.clone()] + [p.grad.clone() for p in sq.parameters()])
+        results[mode] = outs
+    for a, b in zip(results[True], results[False]):
+        for u, v in zip(a, b):
+            assert u.shape == v.shape and float((u - v).abs().max()) <= 2e-5 * float(v.abs().max()) + 1e-12
+    sq.faithful_dataflow = False
+    assert sq.exploit_diagonal == "auto"
+    # DiagApplyFunction's create_graph backward (pure torch) against autograd through _reference_ops, float64
+    g = torch.Generator().manual_seed(3)
+    S, B = 3, 5
+    leaves = [torch.randn(S, B, D, generator=g, dtype=torch.float64), torch.randn(D, generator=g, dtype=torch.float64),
+              torch.randn(D, generator=g, dtype=torch.float64), torch.randn(1 + S, D, generator=g, dtype=torch.float64),
+              torch.randn(1, D, generator=g, dtype=torch.float64)]
+    gout = torch.randn(S, B, D, generator=g, dtype=torch.float64)
+    for relu_in, relu_out in ((False, False), (True, True)):
+        ins = [t.clone().requires_grad_(True) for t in leaves]
+        want = torch.autograd.grad(DiagApplyFunction._reference_ops(*ins, True, relu_in, relu_out), ins, gout)
+
+        class Ctx:
+            saved_tensors = (leaves[0], leaves[1], leaves[2], leaves[3], leaves[4] if relu_out else None)
+            n_samples, mean_plus, bias_shape, needs_input_grad = S, True, (1, D), (True,) * 9
+        Ctx.relu_in, Ctx.relu_out = relu_in, relu_out
+        with torch.enable_grad():
+            got = DiagApplyFunction.backward(Ctx, gout)
+        for u, v in zip(got[:5], want):
+            assert float((u - v).abs().max()) <= 1e-12 * float(v.abs().max()), (relu_in, relu_out)
