@@ -305,8 +305,14 @@ def _reparam(g_mu, g_rho, eps, lambda_):
     """(u (J, 1+S, D), kl (J,) or None): one fused launch on the GPU when a loss is being built (autograd
     on: the KL of this very pass comes for free and its backward is closed-form); the reference's op chain on
     the host and for pure inference (three tiny launches, less host overhead than the custom Function)."""
-    if g_mu.device.type == "cuda" and g_mu.dtype == torch.float32 and torch.is_grad_enabled():
-        return ReparamKLFunction.apply(g_mu, g_rho, eps, lambda_)
+    if g_mu.device.type == "cuda" and g_mu.dtype == torch.float32:
+        if torch.is_grad_enabled():
+            return ReparamKLFunction.apply(g_mu, g_rho, eps, lambda_)
+        # inference: the same one launch, called directly (no autograd Function around it: one ctypes call instead of the
+        # softplus / mul / cat launches, and the pass's KL comes with it)
+        from whvi_amd import _hip
+        u, _, kl = _hip.reparam_kl(g_mu, g_rho, eps, lambda_)
+        return u, kl
     sigma = F.softplus(g_rho)
     return torch.cat((g_mu.unsqueeze(1), sigma.unsqueeze(1) * eps), dim=1), None
 
