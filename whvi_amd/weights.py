@@ -304,7 +304,9 @@ def _mean_plus_rest(t, dim):
 def _reparam(g_mu, g_rho, eps, lambda_):
     """(u (J, 1+S, D), kl (J,) or None): one fused launch on the GPU when a loss is being built (autograd
     on: the KL of this very pass comes for free and its backward is closed-form); the reference's op chain on
-    the host and for pure inference (three tiny launches, less host overhead than the custom Function)."""
+    the host and for pure inference (three tiny launches: less host overhead than the custom Function, and -- measured
+    again in round 4 -- than a direct call of the kernel's ctypes wrapper: toy network's eager 64-sample pass 0.195 vs 0.236 ms;
+    a hipGraph replay of the same pass would gain from the single launch, 0.075 -> 0.062 ms)."""
     if g_mu.device.type == "cuda" and g_mu.dtype == torch.float32:
         if torch.is_grad_enabled():
             return ReparamKLFunction.apply(g_mu, g_rho, eps, lambda_)
