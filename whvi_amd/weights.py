@@ -307,14 +307,8 @@ def _reparam(g_mu, g_rho, eps, lambda_):
     the host and for pure inference (three tiny launches: less host overhead than the custom Function, and -- measured
     again in round 4 -- than a direct call of the kernel's ctypes wrapper: toy network's eager 64-sample pass 0.195 vs 0.236 ms;
     a hipGraph replay of the same pass would gain from the single launch, 0.075 -> 0.062 ms)."""
-    if g_mu.device.type == "cuda" and g_mu.dtype == torch.float32:
-        if torch.is_grad_enabled():
-            return ReparamKLFunction.apply(g_mu, g_rho, eps, lambda_)
-        # inference: the same one launch, called directly (no autograd Function around it: one ctypes call instead of the
-        # softplus / mul / cat launches, and the pass's KL comes with it)
-        from whvi_amd import _hip
-        u, _, kl = _hip.reparam_kl(g_mu, g_rho, eps, lambda_)
-        return u, kl
+    if g_mu.device.type == "cuda" and g_mu.dtype == torch.float32 and torch.is_grad_enabled():
+        return ReparamKLFunction.apply(g_mu, g_rho, eps, lambda_)
     sigma = F.softplus(g_rho)
     return torch.cat((g_mu.unsqueeze(1), sigma.unsqueeze(1) * eps), dim=1), None
 
