@@ -306,9 +306,16 @@ def _reparam(g_mu, g_rho, eps, lambda_):
     on: the KL of this very pass comes for free and its backward is closed-form); the reference's op chain on
     the host and for pure inference (three tiny launches: less host overhead than the custom Function, and -- measured
     again in round 4 -- than a direct call of the kernel's ctypes wrapper: toy network's eager 64-sample pass 0.195 vs 0.236 ms;
-    a hipGraph replay of the same pass would gain from the single launch, 0.075 -> 0.062 ms)."""
-    if g_mu.device.type == "cuda" and g_mu.dtype == torch.float32 and torch.is_grad_enabled():
-        return ReparamKLFunction.apply(g_mu, g_rho, eps, lambda_)
+    a hipGraph replay of the same pass gains from the single launch, 0.075 -> 0.062 ms: taken while a capture is recording)."""
+    if g_mu.device.type == "cuda" and g_mu.dtype == torch.float32:
+        if torch.is_grad_enabled():
+            return ReparamKLFunction.apply(g_mu, g_rho, eps, lambda_)
+        if torch.cuda.is_current_stream_capturing():
+            # inference pass being recorded into a hipGraph (GraphedPredictor): host overhead is paid once, launches on every
+            # replay -- the one-launch kernel called directly
+            from whvi_amd import _hip
+            u, _, kl = _hip.reparam_kl(g_mu, g_rho, eps, lambda_)
+            return u, kl
     sigma = F.softplus(g_rho)
     return torch.cat((g_mu.unsqueeze(1), sigma.unsqueeze(1) * eps), dim=1), None
 
