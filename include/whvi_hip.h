@@ -268,8 +268,9 @@ int whvi_wbar_bwd_f64(void *grad_u, void *part_s1, void *part_s2, const void *gr
  * to one product per output.  This entry computes that product directly, with the roundings of the as-written chain in the
  * same order ( v = u_i * s2_i;  D * v exact;  s1_i * .;  mean + sample;  h * w;  + bias ):
  *     out[k, b, i] = x[(k,) b, i] * ( wd(u[0])_i + wd(u[1 + k])_i ) + bias[i],     wd(u)_i = s1_i * (D * (u_i * s2_i)),
- * value-identical to the matrix route (weight construction + GEMM) for every input; the sign of a ZERO result is the
- * product's, where the GEMM's sum of D signed zeros usually gives +0.  Non-finite operands are propagated as the matrix
+ * identical to the matrix route (weight construction + GEMM) for every input -- bit for bit against rocBLAS on MI355X, zeros
+ * included: the product is added to +0, the value the other D - 1 products (exact zeros) sum to in a GEMM's +0-initialised
+ * accumulator, so a product of -0 comes out as +0 like there.  Non-finite operands are propagated as the matrix
  * route propagates them: a row of x holding an inf / NaN at column j makes every other output of that row NaN (inf * 0 in
  * the dot product), a non-finite s1_i or an overflowing partial sum of the second transform (|D/2 * u_i * s2_i| = inf) makes
  * output column i NaN.

@@ -80,10 +80,16 @@ def test_value_identical_to_the_matrix_route(dtype, D, S, B, shared, hip_lib):
     s1, s2, u, bias, g = _operands(dtype, D, S, 7 * D + S)
     x = torch.randn((B, D) if shared else (S, B, D), device=DEV, dtype=dtype, generator=g)
     keep = x.clone()
+    x.view(-1, D)[1, : D // 2] = 0.0                              # exact zeros of both signs among the activations (a ReLU's output):
+    x.view(-1, D)[2, : D // 2] = -0.0                             # products of -0 whose sign the GEMM's accumulation drops
+    keep = x.clone()
     got = _hip.diag_apply(x, s1, s2, u, bias, n_samples=S)
     assert _hip.last_kernel().startswith("whvi::diag_apply_kernel<")
     want = matrix_route(x, s1, s2, u, bias)
     assert got.shape == (S, B, D) and torch.equal(got, want) and torch.equal(x, keep)
+    ibits = torch.int32 if dtype == torch.float32 else torch.int64
+    nobias, nobias_want = _hip.diag_apply(x, s1, s2, u, None, n_samples=S), matrix_route(x, s1, s2, u, None)
+    assert bool((nobias == 0).any()) and torch.equal(nobias.view(ibits), nobias_want.view(ibits)), "bits, zeros included"
     assert torch.equal(_hip.diag_apply(x, s1, s2, u, None, n_samples=S), matrix_route(x, s1, s2, u, None))
     # direct weight sampling (src/weights.py:104-108): one w_bar per sample, no mean row
     assert torch.equal(_hip.diag_apply(x, s1, s2, u[1:], bias, n_samples=S, mean_plus=False),

@@ -5,8 +5,8 @@
 // EXACTLY D * diag(s1 (.) u (.) s2) (SURVEY.md finding 1): row i of diag(s2) is one-hot, its transform is s2_i * H[i,:]
 // (exact), the row scale makes it +/- v with v = u_i * s2_i (one rounding), the second transform adds those up to D * v at
 // column i (exact doublings) and to exact zeros elsewhere, and s1_i scales the row (one rounding).  The dense product with that
-// matrix therefore adds exact zeros to ONE product per output: for finite operands `h @ W.T` == h (.) diag(W), bit for bit
-// apart from the sign of a zero result.  These kernels compute the diagonal with the same roundings in the same order
+// matrix therefore adds exact zeros to ONE product per output: for finite operands `h @ W.T` == h (.) diag(W) + 0, bit for
+// bit (the + 0 is the accumulator's: it turns a product of -0 into +0).  These kernels compute the diagonal with the same roundings in the same order
 // (wbar_diag below) and apply it as one read + one write of the activations -- no D x D matrix per sample, no GEMM -- and
 // they reproduce what the matrix route does with NON-FINITE operands, which is where "multiply by the diagonal" and
 // "multiply by a matrix with zeros" differ:
@@ -248,8 +248,10 @@ diag_apply_kernel(u32x4 *__restrict__ dst, const u32x4 *x, const T *__restrict__
                 for (int e = 0; e < VEC; ++e) bv[e] = bc[e];
             }
         }
+        // the one non-zero product of the dot product, added to the +0 the other D - 1 products (exact zeros) sum to in a
+        // GEMM's +0-initialised accumulator: a product of -0 comes out as +0 like there (x + 0.0 is not foldable under IEEE rules)
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) r[k][e] = r[k][e] * wv[e];          // the one non-zero product of the dot product
+        for (int e = 0; e < VEC; ++e) r[k][e] = r[k][e] * wv[e] + (A)0;
         if (bias != nullptr) {
 #pragma unroll
             for (int e = 0; e < VEC; ++e) r[k][e] = r[k][e] + bv[e];      // `out + self.bias`, src/weights.py:101-102

@@ -125,7 +125,8 @@ class DiagApplyFunction(torch.autograd.Function):
     roundings of the as-written chain in the same order -- ``u * s2``, ``D * .`` (exact), ``s1 * .``, mean + sample,
     ``h * w``, ``+ bias`` -- hence the same values as weight construction + GEMM for every input, non-finite ones
     included (a row of ``x`` with an inf / NaN turns its other outputs into NaN like the dot products with W's exact
-    zeros do); only the sign of a zero result may differ (the GEMM's sum of signed zeros).
+    zeros do) and zeros too (the product is added to the +0 a GEMM's accumulator holds): bit-identical to the matrix route
+    on MI355X / rocBLAS (tests/test_diag_apply_gpu.py).
 
     ``x``: (S, B, D) or a shared (B, D); ``u``: (1 + S, D) with ``mean_plus`` (the buffer the reparameterisation kernel
     writes) else (S, D); ``s1, s2``: (D,); ``bias``: D elements or None.  Backward: one call (``whvi_diag_apply_bwd``:
