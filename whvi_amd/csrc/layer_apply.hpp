@@ -66,12 +66,11 @@ small_k_apply_kernel(u32x4 *__restrict__ dst, const float *__restrict__ x, const
                     f4 acc;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float a = xv[i][0][0] * wr[c][r][0][0];
+                        float a = 0.0f;                      // a GEMM's +0-initialised accumulator: zero results come out as +0
 #pragma unroll
                         for (int gi = 0; gi < G; ++gi)
 #pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                if (gi != 0 || e != 0) a = __builtin_fmaf(xv[i][gi][e], wr[c][r][gi][e], a);
+                            for (int e = 0; e < 4; ++e) a = __builtin_fmaf(xv[i][gi][e], wr[c][r][gi][e], a);
                         acc[r] = a;
                     }
                     if (bias != nullptr) acc = acc + bv[c];
