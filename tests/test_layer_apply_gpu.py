@@ -33,7 +33,7 @@ def test_small_k_apply_vs_matmul(K, N, S, B, hip_lib):
     idx = torch.arange(N, device=DEV)
     wd[:, idx, idx % K] = w[:, idx, idx % K]
     x[1, 0], x[2, K - 1], x[3, 1] = float("inf"), float("nan"), float("-inf")
-    x[4], x[5, 0] = 0.0, -0.0                                   # zero products of both signs: the GEMM's +0
+    x[4], x[0, 0] = 0.0, -0.0                                   # zero products of both signs: the GEMM's +0
     got, ref = _hip.small_k_apply(x, wd), torch.matmul(x, wd.transpose(1, 2))
     fin = torch.isfinite(ref)
     assert torch.equal(got[fin].view(torch.int32), ref[fin].view(torch.int32)), "bits, zeros included"
