@@ -484,6 +484,12 @@ class WHVISquarePow2Matrix(nn.Module):
 
     def _diag_kernel(self, x, u, bias, n_samples, mean_plus, relu_in=False, relu_out=False):
         """x: (..., D) shared by all samples when ``n_samples`` is None (one sample), else (S, B, D) / (B, D)."""
+        if not torch.is_grad_enabled():          # inference: the launch itself, without an autograd Function around it
+            from whvi_amd import _hip
+            if n_samples is None:
+                return _hip.diag_apply(x.reshape(1, -1, self.D), self.s1, self.s2, u, bias, n_samples=1, mean_plus=mean_plus).view(x.shape)
+            return _hip.diag_apply(x, self.s1, self.s2, u, bias, n_samples=n_samples, mean_plus=mean_plus, relu_in=relu_in,
+                                   relu_out=relu_out)
         if n_samples is None:
             out = DiagApplyFunction.apply(x.reshape(1, -1, self.D), self.s1, self.s2, u, bias, 1, mean_plus)
             return out.view(x.shape)
