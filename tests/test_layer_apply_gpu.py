@@ -127,3 +127,50 @@ def test_argument_checks(hip_lib):
     rd = _hip.lib().whvi_row_dot_f32
     assert rd(out.data_ptr(), x.data_ptr(), w.data_ptr(), None, 2, 8, 13, 0, None) == -2
     assert rd(out.data_ptr(), x.data_ptr(), w.data_ptr(), None, 2, 8, 4, 2, None) == -1
+
+
+def test_relu_folded_into_the_stacked_and_column_launches(monkeypatch, hip_lib):
+    """A 3 -> N -> 1 network (stacked layer, nn.ReLU, transposed column layer -- no square layer in between): the activation is
+    folded into the stacked layer's product (applied before the store).  Same loss and gradients as with the activation as a
+    pass of its own; and each layer's ``forward_mc(relu_in=, relu_out=)`` equals torch.relu around the plain call."""
+    import torch.nn as nn
+    import whvi_amd.networks as networks
+    from whvi_amd.networks import WHVIRegression
+    torch.manual_seed(5)
+    net = WHVIRegression([WHVILinear(3, 64, bias=True), nn.ReLU(), WHVILinear(64, 1, bias=True)], train_samples=4, eval_samples=4)
+    with torch.no_grad():
+        for name, p in net.named_parameters():
+            p.mul_(30.0) if name.endswith(("s1", "s2")) else p.normal_() if name.endswith(("g_mu", "bias")) else None
+    net = net.to(DEV).train()
+    x, y = torch.randn(50, 3, device=DEV), torch.randn(50, 1, device=DEV)
+    calls = []
+    real = WHVIStackedMatrix.forward_mc
+    monkeypatch.setattr(WHVIStackedMatrix, "forward_mc",
+                        lambda self, x_, n, relu_in=False, relu_out=False: (calls.append((relu_in, relu_out)), real(self, x_, n, relu_in, relu_out))[1])
+
+    def run():
+        torch.manual_seed(2)
+        net.zero_grad(set_to_none=True)
+        loss = net.loss(x, y, n=500)
+        loss.backward()
+        return loss.detach(), [p.grad.clone() for p in net.parameters()]
+    fused = run()
+    assert calls == [(False, True)], calls
+    monkeypatch.setattr(networks, "_fuses_relu", lambda module, h: False)
+    plain = run()
+    assert calls[-1] == (False, False)
+    assert abs(float(fused[0]) - float(plain[0])) <= 1e-6 * abs(float(plain[0]))
+    for a, b in zip(fused[1], plain[1]):
+        assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()) + 1e-30
+    monkeypatch.undo()
+    stacked, column = net.sequential[0], net.sequential[2]
+    h = torch.randn(4, 50, 64, device=DEV)
+    with torch.no_grad():
+        for layer, inp, kw in ((stacked, x, dict(relu_out=True)), (stacked, x, dict(relu_in=True, relu_out=True)),
+                               (column, h, dict(relu_in=True)), (column, h, dict(relu_in=True, relu_out=True))):
+            torch.manual_seed(1)
+            got = layer.forward_mc(inp, 4, **kw)
+            torch.manual_seed(1)
+            want = layer.forward_mc(torch.relu(inp) if kw.get("relu_in") else inp, 4)
+            want = torch.relu(want) if kw.get("relu_out") else want
+            assert torch.equal(got, want), kw

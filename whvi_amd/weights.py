@@ -207,19 +207,23 @@ class SmallKApplyFunction(torch.autograd.Function):
     as torch ops (``grad_x = sum_s g[s] @ W[s]``, ``grad_W[s] = g[s].T @ x``)."""
 
     @staticmethod
-    def forward(ctx, x, W, bias=None):
+    def forward(ctx, x, W, bias=None, relu_out=False):
         from whvi_amd import _hip
-        ctx.save_for_backward(x, W)
         ctx.bias_shape = None if bias is None else tuple(bias.shape)
-        return _hip.small_k_apply(x, W, bias)
+        out = _hip.small_k_apply(x, W, bias, relu_out=relu_out)
+        ctx.relu_out = bool(relu_out)
+        ctx.save_for_backward(x, W, out if relu_out else None)          # (the activation's mask comes from its own output)
+        return out
 
     @staticmethod
     def backward(ctx, g):
-        x, W = ctx.saved_tensors
+        x, W, out = ctx.saved_tensors
+        if ctx.relu_out:
+            g = g * (out > 0).to(g.dtype)
         grad_x = torch.matmul(g, W).sum(dim=0) if ctx.needs_input_grad[0] else None
         grad_W = torch.matmul(g.transpose(1, 2), x) if ctx.needs_input_grad[1] else None
         grad_bias = g.sum(dim=(0, 1)).reshape(ctx.bias_shape) if (ctx.bias_shape is not None and ctx.needs_input_grad[2]) else None
-        return grad_x, grad_W, grad_bias
+        return grad_x, grad_W, grad_bias, None
 
 
 class RowDotFunction(torch.autograd.Function):
@@ -227,17 +231,23 @@ class RowDotFunction(torch.autograd.Function):
     (src/weights.py:239-251) as ONE read-only launch (``whvi_row_dot_f32``).  Backward as torch ops."""
 
     @staticmethod
-    def forward(ctx, x, w):
+    def forward(ctx, x, w, relu_in=False):
         from whvi_amd import _hip
         ctx.save_for_backward(x, w)
-        return _hip.row_dot(x, w)
+        ctx.relu_in = bool(relu_in)
+        return _hip.row_dot(x, w, relu_in=relu_in)
 
     @staticmethod
     def backward(ctx, g):
         x, w = ctx.saved_tensors
-        grad_x = g * w.unsqueeze(1) if ctx.needs_input_grad[0] else None
-        grad_w = torch.matmul(x.transpose(1, 2), g).squeeze(-1) if ctx.needs_input_grad[1] else None
-        return grad_x, grad_w
+        grad_x = grad_w = None
+        if ctx.needs_input_grad[0]:
+            grad_x = g * w.unsqueeze(1)
+            if ctx.relu_in:
+                grad_x = grad_x * (x > 0).to(g.dtype)
+        if ctx.needs_input_grad[1]:
+            grad_w = torch.matmul((torch.relu(x) if ctx.relu_in else x).transpose(1, 2), g).squeeze(-1)
+        return grad_x, grad_w, None
 
 
 class ReparamKLFunction(torch.autograd.Function):
@@ -728,10 +738,21 @@ class WHVIStackedMatrix(nn.Module):
             return h @ W.T
         return torch.cat([weight.sample_lrt(h) for weight in self.weight_matrices], dim=1)
 
-    def forward_mc(self, x, n_samples):
+    def fuses_relu(self, x):
+        """True when the batched pass folds an ``nn.ReLU`` behind this layer into its product's launch (a ReLU in front of it
+        acts on the narrow input and is a negligible op of its own)."""
+        from whvi_amd import _hip
+        return bool(self.hip_apply and x.dim() == 2 and x.device.type == "cuda" and x.dtype == torch.float32
+                    and self.D_in in (4, 8) and _hip.small_k_apply_supported(x.new_empty((1, self.D_in)), self.stack * self.D_in))
+
+    def forward_mc(self, x, n_samples, relu_in=False, relu_out=False):
         """Batched MC forward, see WHVISquarePow2Matrix.forward_mc; ``x``: (batch, n_in) or
         (n_samples, batch, n_in) -> (n_samples, batch, n_out).  Sample k of sub-matrix j uses row
-        ``[j, k]`` of one ``randn(stack, n_samples, D_in)`` draw."""
+        ``[j, k]`` of one ``randn(stack, n_samples, D_in)`` draw.  ``relu_in`` / ``relu_out``: ``relu(layer(relu(x)))``."""
+        if relu_in:
+            x = torch.relu(x)
+        if relu_out and not self.fuses_relu(x):
+            return torch.relu(self.forward_mc(x, n_samples))
         S, J, D = n_samples, self.stack, self.D_in
         dev = self._stacked_device()
         s1, s2 = self._stacked("s1"), self._stacked("s2")
@@ -748,7 +769,7 @@ class WHVIStackedMatrix(nn.Module):
         x_padded[..., :self.n_in] = x
         from whvi_amd import _hip
         if self.hip_apply and _hip.small_k_apply_supported(x_padded, J * D):
-            out = SmallKApplyFunction.apply(x_padded, W, self.bias)                 # one write-only launch (K = D_in = 4 or 8), bias included
+            out = SmallKApplyFunction.apply(x_padded, W, self.bias, relu_out)       # one write-only launch (K = D_in = 4 or 8), bias (and ReLU) included
         else:
             out = torch.matmul(x_padded, W.transpose(1, 2))
             if self.bias is not None:
@@ -800,10 +821,19 @@ class WHVIColumnMatrix(nn.Module):
     def forward(self, x):
         return F.linear(x, self.sample(), self.bias)
 
-    def forward_mc(self, x, n_samples):
+    def fuses_relu(self, x):
+        """True when the batched pass folds an ``nn.ReLU`` in front of this (transposed) layer into its row-dot launch."""
+        from whvi_amd import _hip
+        return bool(self.hip_apply and self.transposed and x.dim() == 3 and self.D == self.weight_submodule.D and _hip.row_dot_supported(x))
+
+    def forward_mc(self, x, n_samples, relu_in=False, relu_out=False):
         """Batched MC forward (direct weight sampling like ``forward``); ``x``: (batch, n_in) or
         (n_samples, batch, n_in) -> (n_samples, batch, n_out).  Only row 0 of every sampled square
-        matrix is ever built."""
+        matrix is ever built.  ``relu_in`` / ``relu_out``: ``relu(layer(relu(x)))``."""
+        if relu_out:
+            return torch.relu(self.forward_mc(x, n_samples, relu_in=relu_in))
+        if relu_in and not (self.fuses_relu(x) and x.shape[0] == n_samples):
+            x, relu_in = torch.relu(x), False
         sq = self.weight_submodule
         u, kl = _draw_and_reparam(self, sq.g_mu.unsqueeze(0), sq.g_rho.unsqueeze(0), n_samples, sq.lambda_)
         self._mc_kl = None if kl is None else kl.squeeze(0)
@@ -816,7 +846,7 @@ class WHVIColumnMatrix(nn.Module):
         if self.transposed:                       # weight (1, D): out = F.linear(x, w[None]) per sample = x @ w: one read of x
             from whvi_amd import _hip
             if self.hip_apply and x.dim() == 3 and x.shape[0] == n_samples and _hip.row_dot_supported(x):
-                out = RowDotFunction.apply(x, w.contiguous())            # one read-only launch for all samples
+                out = RowDotFunction.apply(x, w.contiguous(), relu_in)   # one read-only launch for all samples (ReLU on load)
             else:
                 out = torch.matmul(x, w.unsqueeze(-1))   # batched GEMV (a product + a sum pass moved 2.5x the bytes: 1.6 vs 0.62 ms at config 4)
         else:                                     # weight (D, 1): out = x[..., :1] * w
