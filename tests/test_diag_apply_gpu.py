@@ -368,7 +368,8 @@ def test_network_folds_relu_into_the_square_layer(monkeypatch, hip_lib):
         loss.backward()
         return loss.detach(), [p.grad.clone() for p in net.parameters()]
     fused_loss, fused_grads = run()
-    assert (True, True) in calls, calls                                  # the D = 64 square layer took both activations
+    # both activations are folded: the first into the stacked layer's product (its relu_out), the second into the square layer
+    assert calls == [(False, True)], calls
     calls.clear()
     monkeypatch.setattr(networks, "_fuses_relu", lambda module, h: False)
     plain_loss, plain_grads = run()
